@@ -1,0 +1,475 @@
+"""ctypes front-end of the CPU oracle (oracle/yagi_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py -- never by yagi_amd/.  See the header of
+yagi_oracle.c for what is pinned by the reference's golden vectors and what is
+"parity unpinned".
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_LIB_PATH = _DIR / "libyagi_oracle.so"
+
+
+def build(force: bool = False) -> Path:
+    src = _DIR / "yagi_oracle.c"
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_DIR), "-B", "libyagi_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class cf32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class cf64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(_LIB_PATH))
+        vp, sz, fp = C.c_void_p, C.c_size_t, C.c_float
+        L.yo_dotprod_rrrf.restype = C.c_float
+        L.yo_dotprod_rrrf.argtypes = [vp, vp, sz]
+        L.yo_dotprod_rrrf_f64.restype = C.c_double
+        L.yo_dotprod_rrrf_f64.argtypes = [vp, vp, sz]
+        for n in ("rcc", "crc", "ccc", "crc_f64", "ccc_f64"):
+            f = getattr(L, f"yo_dotprod_{n}")
+            f.restype = None
+            f.argtypes = [vp, vp, sz, vp]
+        for k, coeff in (("rrrf", fp), ("crcf", fp), ("cccf", cf32)):
+            T = fp if k == "rrrf" else cf32
+            g = lambda name: getattr(L, f"yo_{name}")
+            g(f"firfilt_{k}_create").restype = vp
+            g(f"firfilt_{k}_create").argtypes = [vp, sz]
+            g(f"firfilt_{k}_clone").restype = vp
+            g(f"firfilt_{k}_clone").argtypes = [vp]
+            g(f"firfilt_{k}_destroy").argtypes = [vp]
+            g(f"firfilt_{k}_reset").argtypes = [vp]
+            g(f"firfilt_{k}_set_scale").argtypes = [vp, coeff]
+            g(f"firfilt_{k}_push").argtypes = [vp, T]
+            g(f"firfilt_{k}_execute").restype = T
+            g(f"firfilt_{k}_execute").argtypes = [vp]
+            g(f"firfilt_{k}_execute_block").restype = C.c_int
+            g(f"firfilt_{k}_execute_block").argtypes = [vp, vp, sz, vp, sz]
+            g(f"firdecim_{k}_create").restype = vp
+            g(f"firdecim_{k}_create").argtypes = [sz, vp, sz]
+            g(f"firdecim_{k}_destroy").argtypes = [vp]
+            g(f"firdecim_{k}_reset").argtypes = [vp]
+            g(f"firdecim_{k}_set_scale").argtypes = [vp, coeff]
+            g(f"firdecim_{k}_execute").restype = T
+            g(f"firdecim_{k}_execute").argtypes = [vp, vp]
+            g(f"firdecim_{k}_execute_block").restype = None
+            g(f"firdecim_{k}_execute_block").argtypes = [vp, vp, sz, vp]
+            g(f"firpfb_{k}_create").restype = vp
+            g(f"firpfb_{k}_create").argtypes = [sz, vp, sz]
+            g(f"firpfb_{k}_destroy").argtypes = [vp]
+            g(f"firpfb_{k}_reset").argtypes = [vp]
+            g(f"firpfb_{k}_set_scale").argtypes = [vp, coeff]
+            g(f"firpfb_{k}_push").argtypes = [vp, T]
+            g(f"firpfb_{k}_execute").restype = C.c_int
+            g(f"firpfb_{k}_execute").argtypes = [vp, sz, vp]
+            g(f"firpfb_{k}_execute_block").restype = C.c_int
+            g(f"firpfb_{k}_execute_block").argtypes = [vp, sz, vp, sz, vp]
+        L.yo_fir_block_f64.restype = None
+        L.yo_fir_block_f64.argtypes = [C.c_int, vp, sz, vp, vp, sz, sz, sz, vp]
+        L.yo_dft_f64.restype = None
+        L.yo_dft_f64.argtypes = [vp, sz, C.c_int, vp]
+        L.yo_fft_shift.argtypes = [vp, sz]
+        L.yo_fft_plan_create.restype = vp
+        L.yo_fft_plan_create.argtypes = [sz, C.c_int]
+        L.yo_fft_plan_destroy.argtypes = [vp]
+        L.yo_fft_run_f32.restype = None
+        L.yo_fft_run_f32.argtypes = [vp, vp, vp]
+        L.yo_fir_design_kaiser.restype = C.c_int
+        L.yo_fir_design_kaiser.argtypes = [sz, fp, fp, fp, vp]
+        L.yo_besseli0f.restype = fp
+        L.yo_besseli0f.argtypes = [fp]
+        L.yo_gen_real.argtypes = [C.c_uint64, C.c_uint64, sz, vp]
+        L.yo_gen_complex.argtypes = [C.c_uint64, C.c_uint64, sz, vp]
+        L.yo_window_create.restype = vp
+        L.yo_window_create.argtypes = [sz, sz]
+        L.yo_window_destroy.argtypes = [vp]
+        L.yo_window_reset.argtypes = [vp]
+        L.yo_window_read.restype = vp
+        L.yo_window_read.argtypes = [vp]
+        L.yo_window_index.restype = C.c_int
+        L.yo_window_index.argtypes = [vp, sz, vp]
+        L.yo_window_push.argtypes = [vp, vp]
+        L.yo_window_write.argtypes = [vp, vp, sz]
+        L.yo_window_clone.restype = vp
+        L.yo_window_clone.argtypes = [vp]
+        L.yo_window_resize.restype = C.c_int
+        L.yo_window_resize.argtypes = [vp, sz]
+        L.yo_firpfbch_create.restype = vp
+        L.yo_firpfbch_create.argtypes = [sz, sz, vp]
+        L.yo_firpfbch_destroy.argtypes = [vp]
+        L.yo_firpfbch_analyzer_execute.argtypes = [vp, vp, sz, vp]
+        L.yo_firpfbch2_create.restype = vp
+        L.yo_firpfbch2_create.argtypes = [sz, sz, vp]
+        L.yo_firpfbch2_destroy.argtypes = [vp]
+        L.yo_firpfbch2_analyzer_execute.argtypes = [vp, vp, sz, vp]
+        L.yo_stream_fir_fft.argtypes = [vp, vp, vp, sz, vp, vp]
+        _lib = L
+    return _lib
+
+
+# ---------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------
+KINDS = {"rrrf": (np.float32, np.float32, 0), "crcf": (np.complex64, np.float32, 1),
+         "cccf": (np.complex64, np.complex64, 2)}
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dt):
+    return np.ascontiguousarray(np.asarray(a, dtype=dt))
+
+
+def _scalar(kind, v, coeff=False):
+    """numpy scalar -> ctypes by-value argument for T (or Coeff)."""
+    dt = KINDS[kind][1 if coeff else 0]
+    if dt == np.float32:
+        return C.c_float(float(np.real(v)))
+    v = complex(v)
+    return cf32(v.real, v.imag)
+
+
+def _from(kind, v):
+    if isinstance(v, cf32):
+        return np.complex64(complex(v.re, v.im))
+    return np.float32(v)
+
+
+def dotprod(kind, a, b):
+    """kind in rrrf | rcc ([f32].[Complex]) | crc ([Complex].[f32]) | ccc; f32 sequential sum."""
+    L = lib()
+    if kind == "rrrf":
+        a, b = _as(a, np.float32), _as(b, np.float32)
+        return np.float32(L.yo_dotprod_rrrf(_p(a), _p(b), min(len(a), len(b))))
+    dta = np.float32 if kind == "rcc" else np.complex64
+    dtb = np.float32 if kind == "crc" else np.complex64
+    a, b = _as(a, dta), _as(b, dtb)
+    y = np.zeros(1, np.complex64)
+    getattr(L, f"yo_dotprod_{kind}")(_p(a), _p(b), min(len(a), len(b)), _p(y))
+    return y[0]
+
+
+def dotprod_f64(kind, a, b):
+    L = lib()
+    if kind == "rrrf":
+        a, b = _as(a, np.float32), _as(b, np.float32)
+        return L.yo_dotprod_rrrf_f64(_p(a), _p(b), len(a))
+    y = np.zeros(1, np.complex128)
+    if kind == "crc":
+        a, b = _as(a, np.complex64), _as(b, np.float32)
+        L.yo_dotprod_crc_f64(_p(a), _p(b), len(a), _p(y))
+    elif kind == "rcc":
+        a, b = _as(a, np.float32), _as(b, np.complex64)
+        L.yo_dotprod_crc_f64(_p(b), _p(a), len(a), _p(y))
+    else:
+        a, b = _as(a, np.complex64), _as(b, np.complex64)
+        L.yo_dotprod_ccc_f64(_p(a), _p(b), len(a), _p(y))
+    return y[0]
+
+
+class Window:
+    """Restatement of buffer::Window<T> (window.rs:4-92); T = f32 or Complex<f32>."""
+
+    def __init__(self, n, dtype=np.float32, _h=None):
+        self.dtype = np.dtype(dtype)
+        self.L = lib()
+        self.h = _h if _h is not None else self.L.yo_window_create(n, self.dtype.itemsize)
+        if not self.h:
+            raise ValueError("window size must be greater than zero")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_window_destroy(self.h)
+            self.h = None
+
+    def _len(self):
+        # struct layout: v, esz, len, ...
+        return C.cast(self.h, C.POINTER(C.c_size_t))[2]
+
+    def read(self):
+        n = self._len()
+        ptr = self.L.yo_window_read(self.h)
+        buf = (C.c_char * (n * self.dtype.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=self.dtype).copy()
+
+    def push(self, v):
+        a = np.asarray([v], dtype=self.dtype)
+        self.L.yo_window_push(self.h, _p(a))
+
+    def write(self, vals):
+        a = _as(vals, self.dtype)
+        self.L.yo_window_write(self.h, _p(a), len(a))
+
+    def index(self, i):
+        out = np.zeros(1, self.dtype)
+        if self.L.yo_window_index(self.h, i, _p(out)):
+            raise IndexError("index value out of range")
+        return out[0]
+
+    def reset(self):
+        self.L.yo_window_reset(self.h)
+
+    def resize(self, n):
+        if self.L.yo_window_resize(self.h, n):
+            raise ValueError("window size must be greater than zero")
+
+    def clone(self):
+        return Window(0, self.dtype, _h=self.L.yo_window_clone(self.h))
+
+
+class _Obj:
+    fam = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.L, f"yo_{self.fam}_{self.kind}_destroy")(self.h)
+            self.h = None
+
+    def _f(self, name):
+        return getattr(self.L, f"yo_{self.fam}_{self.kind}_{name}")
+
+    def reset(self):
+        self._f("reset")(self.h)
+
+    def set_scale(self, s):
+        self._f("set_scale")(self.h, _scalar(self.kind, s, coeff=True))
+
+
+class FirFilter(_Obj):
+    """Restatement of FirFilter<T,Coeff> (firfilt.rs:10-15,63-79,209-278)."""
+    fam = "firfilt"
+
+    def __init__(self, kind, h, _h=None):
+        self.kind, self.L = kind, lib()
+        self.tdt, self.cdt, _ = KINDS[kind]
+        if _h is not None:
+            self.h = _h
+            return
+        h = _as(h, self.cdt)
+        self.h = self._f("create")(_p(h), len(h))
+        if not self.h:
+            raise ValueError("filter length must be greater than zero")
+
+    def clone(self):
+        return FirFilter(self.kind, None, _h=self._f("clone")(self.h))
+
+    def push(self, x):
+        self._f("push")(self.h, _scalar(self.kind, x))
+
+    def execute(self):
+        return _from(self.kind, self._f("execute")(self.h))
+
+    def execute_one(self, x):
+        self.push(x)
+        return self.execute()
+
+    def execute_block(self, x):
+        x = _as(x, self.tdt)
+        y = np.empty_like(x)
+        rc = self._f("execute_block")(self.h, _p(x), len(x), _p(y), len(y))
+        assert rc == 0
+        return y
+
+
+class FirDecimationFilter(_Obj):
+    """Restatement of FirDecimationFilter<T,Coeff> (firdecim.rs:38-57,179-205)."""
+    fam = "firdecim"
+
+    def __init__(self, kind, M, h):
+        self.kind, self.L, self.M = kind, lib(), M
+        self.tdt, self.cdt, _ = KINDS[kind]
+        h = _as(h, self.cdt)
+        self.h = self._f("create")(M, _p(h), len(h))
+        if not self.h:
+            raise ValueError("config")
+
+    def execute(self, x):
+        x = _as(x, self.tdt)
+        assert len(x) >= self.M
+        return _from(self.kind, self._f("execute")(self.h, _p(x)))
+
+    def execute_block(self, x, n):
+        x = _as(x, self.tdt)
+        assert len(x) >= n * self.M
+        y = np.empty(n, self.tdt)
+        self._f("execute_block")(self.h, _p(x), n, _p(y))
+        return y
+
+
+class FirPfbFilter(_Obj):
+    """Restatement of FirPfbFilter<T,Coeff> (firpfb.rs:34-65,255-301)."""
+    fam = "firpfb"
+
+    def __init__(self, kind, num_filters, h, h_len=None):
+        self.kind, self.L = kind, lib()
+        self.tdt, self.cdt, _ = KINDS[kind]
+        h = _as(h, self.cdt)
+        self.h = self._f("create")(num_filters, _p(h), len(h) if h_len is None else h_len)
+        if not self.h:
+            raise ValueError("config")
+
+    def push(self, x):
+        self._f("push")(self.h, _scalar(self.kind, x))
+
+    def write(self, xs):
+        for v in xs:
+            self.push(v)
+
+    def execute(self, i):
+        y = np.zeros(1, self.tdt)
+        if self._f("execute")(self.h, i, _p(y)):
+            raise ValueError("filterbank index exceeds maximum")
+        return y[0]
+
+    def execute_block(self, i, x):
+        x = _as(x, self.tdt)
+        y = np.empty_like(x)
+        if self._f("execute_block")(self.h, i, _p(x), len(x), _p(y)):
+            raise ValueError("filterbank index exceeds maximum")
+        return y
+
+
+def fir_block_f64(kind, h, x, M=1, n=None, scale=1.0):
+    """f64 truth: y[i] = scale * sum_k h[k] x[i*M-k], zero history."""
+    tdt, cdt, code = KINDS[kind]
+    h, x = _as(h, cdt), _as(x, tdt)
+    if n is None:
+        n = len(x) // M
+    s = _as([scale], cdt)
+    y = np.zeros(n, np.float64 if kind == "rrrf" else np.complex128)
+    lib().yo_fir_block_f64(code, _p(h), len(h), _p(s), _p(x), len(x), M, n, _p(y))
+    return y
+
+
+def dft_f64(x, backward=False):
+    x = _as(x, np.complex64)
+    y = np.zeros(len(x), np.complex128)
+    lib().yo_dft_f64(_p(x), len(x), 1 if backward else 0, _p(y))
+    return y
+
+
+def fft_shift(v):
+    v = _as(v, np.complex64).copy()
+    lib().yo_fft_shift(_p(v), len(v))
+    return v
+
+
+class FftPlanF32:
+    """f32 radix-4 power-of-two FFT (timed CPU baseline; fft/mod.rs:39-48 semantics)."""
+
+    def __init__(self, n, backward=False):
+        self.L, self.n = lib(), n
+        self.h = self.L.yo_fft_plan_create(n, 1 if backward else 0)
+        if not self.h:
+            raise ValueError("power of two only")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_fft_plan_destroy(self.h)
+            self.h = None
+
+    def run(self, x):
+        x = _as(x, np.complex64)
+        y = np.empty_like(x)
+        for f in range(len(x) // self.n):
+            self.L.yo_fft_run_f32(self.h, _p(x[f * self.n:]), _p(y[f * self.n:]))
+        return y
+
+
+def fir_design_kaiser(n, fc, as_, mu=0.0):
+    h = np.zeros(max(n, 1), np.float32)
+    if lib().yo_fir_design_kaiser(n, fc, as_, mu, _p(h)):
+        raise ValueError("config")
+    return h[:n]
+
+
+def gen_real(seed, n, first=0):
+    x = np.empty(n, np.float32)
+    lib().yo_gen_real(seed, first, n, _p(x))
+    return x
+
+
+def gen_complex(seed, n, first=0):
+    x = np.empty(n, np.complex64)
+    lib().yo_gen_complex(seed, first, n, _p(x))
+    return x
+
+
+class FirPfbCh:
+    """firpfbch analyzer restatement (PARITY UNPINNED: absent from the reference)."""
+
+    def __init__(self, M, p, h):
+        self.L, self.M, self.p = lib(), M, p
+        h = _as(h, np.float32)
+        assert len(h) >= M * p
+        self.h = self.L.yo_firpfbch_create(M, p, _p(h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_firpfbch_destroy(self.h)
+            self.h = None
+
+    def analyzer_execute(self, x):
+        x = _as(x, np.complex64)
+        nf = len(x) // self.M
+        y = np.empty(nf * self.M, np.complex64)
+        self.L.yo_firpfbch_analyzer_execute(self.h, _p(x), nf, _p(y))
+        return y.reshape(nf, self.M)
+
+
+class FirPfbCh2:
+    """firpfbch2 analyzer restatement (PARITY UNPINNED: absent from the reference)."""
+
+    def __init__(self, M, m, h):
+        self.L, self.M, self.m = lib(), M, m
+        h = _as(h, np.float32)
+        assert len(h) >= 2 * M * m
+        self.h = self.L.yo_firpfbch2_create(M, m, _p(h))
+        if not self.h:
+            raise ValueError("config")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_firpfbch2_destroy(self.h)
+            self.h = None
+
+    def analyzer_execute(self, x):
+        x = _as(x, np.complex64)
+        ns = len(x) // (self.M // 2)
+        y = np.empty(ns * self.M, np.complex64)
+        self.L.yo_firpfbch2_analyzer_execute(self.h, _p(x), ns, _p(y))
+        return y.reshape(ns, self.M)
+
+
+def stream_fir_fft(h, scale, x, nfft):
+    """headline composition: firfilt_crcf.execute_block -> nfft frames -> forward f32 FFT."""
+    L = lib()
+    q = FirFilter("crcf", h)
+    q.set_scale(scale)
+    plan = FftPlanF32(nfft)
+    x = _as(x, np.complex64)
+    nf = len(x) // nfft
+    scratch = np.empty(nfft, np.complex64)
+    out = np.empty(nf * nfft, np.complex64)
+    L.yo_stream_fir_fft(q.h, plan.h, _p(x), nf, _p(scratch), _p(out))
+    return out.reshape(nf, nfft)

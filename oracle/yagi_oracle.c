@@ -1,0 +1,633 @@
+/*
+ * yagi_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C CPU restatement of the yagi (EEGKit/yagi, Rust) algorithms on the FIR/FFT hot
+ * path.  It exists to CHECK the HIP kernels (tests/, __graft_entry__.smoke()) and to be
+ * timed as the "cpu_baseline" leg of bench.py.  Nothing under yagi_amd/ may import, link
+ * or call it; the product path fails loudly when the HIP library is missing.
+ *
+ * Parity status:
+ *   - dotprod / firfilt / firdecim / firpfb / Window: restated line by line from the
+ *     reference and PINNED by the reference's own golden vectors (the .npz fixtures under tests/golden,
+ *     tests/test_oracle_golden.py).
+ *   - fft: the reference delegates the arithmetic to the third-party crate
+ *     rustfft = "6.2.0" (Cargo.toml:21; Cargo.lock is git-ignored), whose source is not
+ *     under /root/reference.  The oracle is therefore the *definition* the reference's
+ *     tests pin (unnormalised DFT, forward = e^{-j2pi nk/N}): an f64 O(N^2) DFT, checked
+ *     against all 33 FFT_TEST_{X,Y}N golden pairs (N <= 509).  At N = 4096 the reference
+ *     holds no vector: PARITY UNPINNED by the reference there, pinned by definition only.
+ *   - firpfbch / firpfbch2: the reference module is empty (src/multichannel/mod.rs, 0
+ *     lines).  PARITY UNPINNED; the restatement below composes the reference's own
+ *     FirPfb-style branch split + Window + dotprod + Fft following liquid-dsp's published
+ *     firpfbch.c / firpfbch2.c semantics and is pinned by property tests only.
+ *   - The reference is Rust and no Rust toolchain exists here: there is no oracle/_ref.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (Rust never contracts a*b+c into an FMA
+ * and never reassociates), see oracle/Makefile.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference root).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float re, im; } cf32;   /* num_complex::Complex<f32>, #[repr(C)] */
+typedef struct { double re, im; } cf64;
+
+#define YO_OK 0
+#define YO_ECONFIG 2
+#define YO_ERANGE 4
+
+/* ------------------------------------------------------------------------------------
+ * scalar arithmetic exactly as num-complex spells it (no FMA, no reassociation)
+ * ---------------------------------------------------------------------------------- */
+static inline cf32 c_add(cf32 a, cf32 b) { cf32 r = { a.re + b.re, a.im + b.im }; return r; }
+/* Complex<f32> * f32  and  f32 * Complex<f32>  (component-wise, commutative bit for bit) */
+static inline cf32 c_mulr(cf32 a, float b) { cf32 r = { a.re * b, a.im * b }; return r; }
+/* Complex * Complex: (ar*br - ai*bi, ar*bi + ai*br) */
+static inline cf32 c_mul(cf32 a, cf32 b) {
+    cf32 r = { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re };
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------
+ * dotprod  --  src/dotprod/mod.rs:19-73 (default build: iter().zip().map(a*b).sum(),
+ * i.e. a strictly sequential left-to-right f32 accumulation starting from zero)
+ * ---------------------------------------------------------------------------------- */
+float yo_dotprod_rrrf(const float *a, const float *b, size_t n) {          /* :19-31 */
+    float s = 0.0f;
+    for (size_t i = 0; i < n; i++) s = s + a[i] * b[i];
+    return s;
+}
+void yo_dotprod_rcc(const float *a, const cf32 *b, size_t n, cf32 *y) {    /* :33-45 */
+    cf32 s = { 0.0f, 0.0f };
+    for (size_t i = 0; i < n; i++) s = c_add(s, c_mulr(b[i], a[i]));
+    *y = s;
+}
+void yo_dotprod_crc(const cf32 *a, const float *b, size_t n, cf32 *y) {    /* :47-59 */
+    cf32 s = { 0.0f, 0.0f };
+    for (size_t i = 0; i < n; i++) s = c_add(s, c_mulr(a[i], b[i]));
+    *y = s;
+}
+void yo_dotprod_ccc(const cf32 *a, const cf32 *b, size_t n, cf32 *y) {     /* :61-73 */
+    cf32 s = { 0.0f, 0.0f };
+    for (size_t i = 0; i < n; i++) s = c_add(s, c_mul(a[i], b[i]));
+    *y = s;
+}
+/* f64 truth for the same inner products (products and sums in double) */
+double yo_dotprod_rrrf_f64(const float *a, const float *b, size_t n) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; i++) s += (double)a[i] * (double)b[i];
+    return s;
+}
+void yo_dotprod_crc_f64(const cf32 *a, const float *b, size_t n, cf64 *y) {
+    double sr = 0, si = 0;
+    for (size_t i = 0; i < n; i++) { sr += (double)a[i].re * b[i]; si += (double)a[i].im * b[i]; }
+    y->re = sr; y->im = si;
+}
+void yo_dotprod_ccc_f64(const cf32 *a, const cf32 *b, size_t n, cf64 *y) {
+    double sr = 0, si = 0;
+    for (size_t i = 0; i < n; i++) {
+        sr += (double)a[i].re * b[i].re - (double)a[i].im * b[i].im;
+        si += (double)a[i].re * b[i].im + (double)a[i].im * b[i].re;
+    }
+    y->re = sr; y->im = si;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Window<T>  --  src/buffer/window.rs:4-92 ; msb_index src/utility/bits.rs:110-112
+ * (element size generic: elements are `esz` bytes, copied with memcpy)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    unsigned char *v;
+    size_t esz, len, n, mask, read_index, num_allocated;
+} yo_window;
+
+static unsigned msb_index(uint32_t x) {                /* bits.rs:110-112 */
+    unsigned lz = 0;
+    if (x == 0) return 0;
+    while (!(x & 0x80000000u)) { x <<= 1; lz++; }
+    return 32 - lz;
+}
+
+yo_window *yo_window_create(size_t n, size_t esz) {     /* window.rs:13-34 */
+    if (n == 0) return NULL;                            /* Error::Config */
+    yo_window *w = (yo_window *)calloc(1, sizeof(*w));
+    unsigned m = msb_index((uint32_t)n);
+    w->esz = esz; w->len = n; w->n = (size_t)1 << m; w->mask = w->n - 1;
+    w->num_allocated = w->n + n - 1;
+    w->v = (unsigned char *)calloc(w->num_allocated, esz);
+    w->read_index = 0;
+    return w;
+}
+void yo_window_destroy(yo_window *w) { if (w) { free(w->v); free(w); } }
+void yo_window_reset(yo_window *w) {                    /* :61-64 */
+    w->read_index = 0;
+    memset(w->v, 0, w->num_allocated * w->esz);
+}
+const void *yo_window_read(const yo_window *w) {        /* :66-68 contiguous, OLDEST first */
+    return w->v + w->read_index * w->esz;
+}
+int yo_window_index(const yo_window *w, size_t i, void *out) {   /* :70-75 */
+    if (i >= w->len) return YO_ERANGE;
+    memcpy(out, w->v + (w->read_index + i) * w->esz, w->esz);
+    return YO_OK;
+}
+void yo_window_push(yo_window *w, const void *value) {  /* :77-85 */
+    w->read_index = (w->read_index + 1) & w->mask;
+    if (w->read_index == 0)
+        memmove(w->v, w->v + w->n * w->esz, (w->len - 1) * w->esz);
+    memcpy(w->v + (w->read_index + w->len - 1) * w->esz, value, w->esz);
+}
+void yo_window_write(yo_window *w, const void *values, size_t count) {   /* :87-91 */
+    const unsigned char *p = (const unsigned char *)values;
+    for (size_t i = 0; i < count; i++) yo_window_push(w, p + i * w->esz);
+}
+yo_window *yo_window_clone(const yo_window *s) {        /* #[derive(Clone)] :3 */
+    yo_window *w = (yo_window *)malloc(sizeof(*w));
+    *w = *s;
+    w->v = (unsigned char *)malloc(s->num_allocated * s->esz);
+    memcpy(w->v, s->v, s->num_allocated * s->esz);
+    return w;
+}
+int yo_window_resize(yo_window *w, size_t n) {          /* :36-59 */
+    if (n == w->len) return YO_OK;
+    yo_window *nw = yo_window_create(n, w->esz);
+    if (!nw) return YO_ECONFIG;
+    unsigned char tmp[16] = { 0 }, val[16];
+    if (n > w->len) {
+        for (size_t i = 0; i < n - w->len; i++) yo_window_push(nw, tmp);
+        for (size_t i = 0; i < w->len; i++) { yo_window_index(w, i, val); yo_window_push(nw, val); }
+    } else {
+        for (size_t i = w->len - n; i < w->len; i++) { yo_window_index(w, i, val); yo_window_push(nw, val); }
+    }
+    free(w->v);
+    *w = *nw;
+    free(nw);
+    return YO_OK;
+}
+
+/* ------------------------------------------------------------------------------------
+ * FirFilter / FirDecimationFilter / FirPfbFilter for the three type combinations.
+ * One macro instantiates the restatement for (T, Coeff) = (f32,f32) "rrrf",
+ * (Complex32,f32) "crcf", (Complex32,Complex32) "cccf".
+ *
+ * FirFilter state is a VecDeque<T> created full (firfilt.rs:72), so push() =
+ * rotate_right(1) + w[0]=x (firfilt.rs:220-223) just moves `head` back by one and
+ * overwrites the oldest slot; as_slices() (dotprod/mod.rs:99-108) splits the logical
+ * sequence at cap-head.  The ring below reproduces that physical layout so the two
+ * partial sums associate exactly as the reference's do.
+ * ---------------------------------------------------------------------------------- */
+#define DEFINE_FIR(SUF, T, C, MUL_TC, ADD_T, ZERO_T, ONE_C)                                   \
+typedef struct { C *h; size_t h_len; T *w; size_t head; C scale; } yo_firfilt_##SUF;          \
+                                                                                              \
+yo_firfilt_##SUF *yo_firfilt_##SUF##_create(const C *h, size_t h_len) { /* firfilt.rs:63-79 */\
+    if (h_len == 0) return NULL;                                                              \
+    yo_firfilt_##SUF *q = (yo_firfilt_##SUF *)calloc(1, sizeof(*q));                          \
+    q->h = (C *)malloc(h_len * sizeof(C)); memcpy(q->h, h, h_len * sizeof(C));                \
+    q->h_len = h_len; q->w = (T *)calloc(h_len, sizeof(T)); q->head = 0; q->scale = ONE_C;    \
+    return q;                                                                                 \
+}                                                                                             \
+void yo_firfilt_##SUF##_destroy(yo_firfilt_##SUF *q) { if (q) { free(q->h); free(q->w); free(q); } } \
+yo_firfilt_##SUF *yo_firfilt_##SUF##_clone(const yo_firfilt_##SUF *s) { /* derive(Clone) :8 */\
+    yo_firfilt_##SUF *q = yo_firfilt_##SUF##_create(s->h, s->h_len);                          \
+    memcpy(q->w, s->w, s->h_len * sizeof(T)); q->head = s->head; q->scale = s->scale;         \
+    return q;                                                                                 \
+}                                                                                             \
+void yo_firfilt_##SUF##_reset(yo_firfilt_##SUF *q) {                  /* :209-213 */          \
+    /* reset() zeroes elements in place; the ring position is kept */                         \
+    for (size_t i = 0; i < q->h_len; i++) q->w[i] = ZERO_T;                                   \
+}                                                                                             \
+void yo_firfilt_##SUF##_set_scale(yo_firfilt_##SUF *q, C s) { q->scale = s; } /* :285 */      \
+void yo_firfilt_##SUF##_push(yo_firfilt_##SUF *q, T x) {              /* :220-223 */          \
+    q->head = (q->head == 0) ? q->h_len - 1 : q->head - 1;                                    \
+    q->w[q->head] = x;                                                                        \
+}                                                                                             \
+T yo_firfilt_##SUF##_execute(const yo_firfilt_##SUF *q) {             /* :241-246 */          \
+    size_t split = q->h_len - q->head;      /* l = buf[head..cap], r = buf[0..head] */        \
+    T l = ZERO_T, r = ZERO_T;                                                                 \
+    for (size_t k = 0; k < split; k++) l = ADD_T(l, MUL_TC(q->w[q->head + k], q->h[k]));      \
+    for (size_t k = split; k < q->h_len; k++) r = ADD_T(r, MUL_TC(q->w[k - split], q->h[k])); \
+    return MUL_TC(ADD_T(l, r), q->scale);                                                     \
+}                                                                                             \
+int yo_firfilt_##SUF##_execute_block(yo_firfilt_##SUF *q, const T *x, size_t nx,              \
+                                     T *y, size_t ny) {               /* :267-278 */          \
+    if (nx != ny) return YO_ECONFIG;                                                          \
+    for (size_t i = 0; i < nx; i++) { yo_firfilt_##SUF##_push(q, x[i]); y[i] = yo_firfilt_##SUF##_execute(q); } \
+    return YO_OK;                                                                             \
+}                                                                                             \
+                                                                                              \
+/* ---- FirDecimationFilter: firdecim.rs:12-17,38-57,179-205 ---- */                          \
+typedef struct { C *h; size_t h_len, M; yo_window *w; C scale; } yo_firdecim_##SUF;           \
+yo_firdecim_##SUF *yo_firdecim_##SUF##_create(size_t M, const C *h, size_t h_len) {           \
+    if (h_len == 0 || M == 0) return NULL;                             /* :39-44 */           \
+    yo_firdecim_##SUF *q = (yo_firdecim_##SUF *)calloc(1, sizeof(*q));                        \
+    q->h = (C *)malloc(h_len * sizeof(C));                                                    \
+    for (size_t i = 0; i < h_len; i++) q->h[i] = h[h_len - 1 - i];     /* :47 reversed */     \
+    q->h_len = h_len; q->M = M; q->w = yo_window_create(h_len, sizeof(T)); q->scale = ONE_C;  \
+    return q;                                                                                 \
+}                                                                                             \
+void yo_firdecim_##SUF##_destroy(yo_firdecim_##SUF *q) { if (q) { free(q->h); yo_window_destroy(q->w); free(q); } } \
+void yo_firdecim_##SUF##_reset(yo_firdecim_##SUF *q) { yo_window_reset(q->w); }               \
+void yo_firdecim_##SUF##_set_scale(yo_firdecim_##SUF *q, C s) { q->scale = s; }               \
+T yo_firdecim_##SUF##_execute(yo_firdecim_##SUF *q, const T *x) {      /* :179-191 */         \
+    T y = ZERO_T;                                                                             \
+    for (size_t i = 0; i < q->M; i++) {                                                       \
+        yo_window_push(q->w, &x[i]);                                                          \
+        if (i == 0) {                                                                         \
+            const T *r = (const T *)yo_window_read(q->w);                                     \
+            T s = ZERO_T;                          /* [Coeff]·[T]: sum of h[k]*r[k] */         \
+            for (size_t k = 0; k < q->h_len; k++) s = ADD_T(s, MUL_TC(r[k], q->h[k]));        \
+            y = MUL_TC(s, q->scale);                                                          \
+        }                                                                                     \
+    }                                                                                         \
+    return y;                                                                                 \
+}                                                                                             \
+void yo_firdecim_##SUF##_execute_block(yo_firdecim_##SUF *q, const T *x, size_t n, T *y) {    \
+    for (size_t i = 0; i < n; i++) y[i] = yo_firdecim_##SUF##_execute(q, x + i * q->M); /* :200-205 */ \
+}                                                                                             \
+                                                                                              \
+/* ---- FirPfbFilter: firpfb.rs:10-15,34-65,255-301 ---- */                                   \
+typedef struct { size_t num_filters, h_sub_len; yo_window *w; C *filters; C scale; } yo_firpfb_##SUF; \
+yo_firpfb_##SUF *yo_firpfb_##SUF##_create(size_t num_filters, const C *h, size_t h_len) {     \
+    if (num_filters == 0 || h_len == 0) return NULL;                   /* :35-40 */           \
+    size_t hs = h_len / num_filters;                                   /* :42 floor */        \
+    if (hs == 0) return NULL;                       /* Window::new(0) -> Err (window.rs:14) */\
+    yo_firpfb_##SUF *q = (yo_firpfb_##SUF *)calloc(1, sizeof(*q));                            \
+    q->num_filters = num_filters; q->h_sub_len = hs;                                          \
+    q->filters = (C *)malloc(num_filters * hs * sizeof(C));                                   \
+    for (size_t i = 0; i < num_filters; i++)                                                  \
+        for (size_t n = 0; n < hs; n++)                                                       \
+            q->filters[i * hs + (hs - n - 1)] = h[i + n * num_filters];  /* :45-52 */         \
+    q->w = yo_window_create(hs, sizeof(T)); q->scale = ONE_C;                                 \
+    return q;                                                                                 \
+}                                                                                             \
+void yo_firpfb_##SUF##_destroy(yo_firpfb_##SUF *q) { if (q) { free(q->filters); yo_window_destroy(q->w); free(q); } } \
+void yo_firpfb_##SUF##_reset(yo_firpfb_##SUF *q) { yo_window_reset(q->w); }                   \
+void yo_firpfb_##SUF##_set_scale(yo_firpfb_##SUF *q, C s) { q->scale = s; }                   \
+void yo_firpfb_##SUF##_push(yo_firpfb_##SUF *q, T x) { yo_window_push(q->w, &x); } /* :255 */ \
+int yo_firpfb_##SUF##_execute(yo_firpfb_##SUF *q, size_t i, T *y) {    /* :277-286 */         \
+    if (i >= q->num_filters) return YO_ECONFIG;                                               \
+    const T *r = (const T *)yo_window_read(q->w);                                             \
+    const C *f = q->filters + i * q->h_sub_len;                                               \
+    T s = ZERO_T;                                                                             \
+    for (size_t k = 0; k < q->h_sub_len; k++) s = ADD_T(s, MUL_TC(r[k], f[k]));               \
+    *y = MUL_TC(s, q->scale);                                                                 \
+    return YO_OK;                                                                             \
+}                                                                                             \
+int yo_firpfb_##SUF##_execute_block(yo_firpfb_##SUF *q, size_t i, const T *x, size_t n, T *y) { /* :295-301 */ \
+    for (size_t k = 0; k < n; k++) {                                                          \
+        yo_firpfb_##SUF##_push(q, x[k]);                                                      \
+        int rc = yo_firpfb_##SUF##_execute(q, i, &y[k]);                                      \
+        if (rc) return rc;                                                                    \
+    }                                                                                         \
+    return YO_OK;                                                                             \
+}
+
+static inline float r_add(float a, float b) { return a + b; }
+static inline float r_mul(float a, float b) { return a * b; }
+static const cf32 CZERO = { 0.0f, 0.0f };
+static const cf32 CONE = { 1.0f, 0.0f };
+
+DEFINE_FIR(rrrf, float, float, r_mul, r_add, 0.0f, 1.0f)
+DEFINE_FIR(crcf, cf32, float, c_mulr, c_add, CZERO, 1.0f)
+DEFINE_FIR(cccf, cf32, cf32, c_mul, c_add, CZERO, CONE)
+
+/* ------------------------------------------------------------------------------------
+ * f64 truth for the whole FIR family: y[i] = scale * sum_k h[k] * x[i*M + phase - k],
+ * zero history.  kind: 0 rrrf, 1 crcf, 2 cccf.
+ * x has nx samples; y gets n outputs; decimation M >= 1; out is interleaved double
+ * (1 double per output for rrrf, 2 otherwise).
+ * ---------------------------------------------------------------------------------- */
+void yo_fir_block_f64(int kind, const float *h, size_t L, const float *scale,
+                      const float *x, size_t nx, size_t M, size_t n, double *y) {
+    for (size_t i = 0; i < n; i++) {
+        size_t c = i * M;                     /* newest input index feeding this output */
+        double sr = 0.0, si = 0.0;
+        for (size_t k = 0; k < L && k <= c; k++) {
+            size_t j = c - k;
+            if (j >= nx) continue;
+            if (kind == 0) sr += (double)h[k] * x[j];
+            else if (kind == 1) { sr += (double)h[k] * x[2 * j]; si += (double)h[k] * x[2 * j + 1]; }
+            else {
+                double hr = h[2 * k], hi = h[2 * k + 1], xr = x[2 * j], xi = x[2 * j + 1];
+                sr += hr * xr - hi * xi; si += hr * xi + hi * xr;
+            }
+        }
+        if (kind == 0) y[i] = sr * scale[0];
+        else if (kind == 1) { y[2 * i] = sr * scale[0]; y[2 * i + 1] = si * scale[0]; }
+        else {
+            double cr = scale[0], ci = scale[1];
+            y[2 * i] = sr * cr - si * ci; y[2 * i + 1] = sr * ci + si * cr;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * FFT.  src/fft/mod.rs:13-26,39-57: unnormalised, Forward = e^{-j 2 pi n k / N},
+ * Backward = e^{+...}; run() is out of place; shift() swaps halves (odd n: the last
+ * element stays).  dir: 0 forward, 1 backward.
+ * ---------------------------------------------------------------------------------- */
+void yo_dft_f64(const cf32 *x, size_t n, int dir, cf64 *y) {   /* the definition; O(n^2) */
+    cf64 *tw = (cf64 *)malloc(n * sizeof(cf64));
+    const double s = dir ? 1.0 : -1.0;
+    for (size_t m = 0; m < n; m++) {
+        double a = s * 2.0 * M_PI * (double)m / (double)n;
+        tw[m].re = cos(a); tw[m].im = sin(a);
+    }
+    for (size_t k = 0; k < n; k++) {
+        double sr = 0, si = 0;
+        size_t m = 0;
+        for (size_t j = 0; j < n; j++) {
+            sr += x[j].re * tw[m].re - x[j].im * tw[m].im;
+            si += x[j].re * tw[m].im + x[j].im * tw[m].re;
+            m += k; if (m >= n) m -= n;
+        }
+        y[k].re = sr; y[k].im = si;
+    }
+    free(tw);
+}
+
+void yo_fft_shift(cf32 *v, size_t n) {                         /* fft/mod.rs:50-57 */
+    size_t n2 = (n % 2 == 0) ? n / 2 : (n - 1) / 2;
+    for (size_t i = 0; i < n2; i++) { cf32 t = v[i]; v[i] = v[i + n2]; v[i + n2] = t; }
+}
+
+/* f32 power-of-two FFT used as the timed CPU baseline for 4096-point transforms: an
+ * iterative decimation-in-time radix-4 (radix-2 first pass when log2 n is odd), the
+ * published structure of rustfft's scalar Radix4 plan (what FftPlanner picks for 2^k
+ * without SIMD).  Plan = digit-reversal table + twiddles computed in f64. */
+typedef struct { size_t n; int dir; uint32_t *rev; cf32 *tw; } yo_fft_plan;
+
+yo_fft_plan *yo_fft_plan_create(size_t n, int dir) {
+    if (n == 0 || (n & (n - 1))) return NULL;
+    yo_fft_plan *p = (yo_fft_plan *)calloc(1, sizeof(*p));
+    p->n = n; p->dir = dir;
+    p->rev = (uint32_t *)malloc(n * sizeof(uint32_t));
+    p->tw = (cf32 *)malloc(n * sizeof(cf32));
+    unsigned lg = 0; while (((size_t)1 << lg) < n) lg++;
+    for (size_t i = 0; i < n; i++) {       /* plain bit reversal */
+        size_t r = 0;
+        for (unsigned b = 0; b < lg; b++) if (i & ((size_t)1 << b)) r |= (size_t)1 << (lg - 1 - b);
+        p->rev[i] = (uint32_t)r;
+    }
+    const double s = dir ? 1.0 : -1.0;
+    for (size_t m = 0; m < n; m++) {
+        double a = s * 2.0 * M_PI * (double)m / (double)n;
+        p->tw[m].re = (float)cos(a); p->tw[m].im = (float)sin(a);
+    }
+    return p;
+}
+void yo_fft_plan_destroy(yo_fft_plan *p) { if (p) { free(p->rev); free(p->tw); free(p); } }
+
+/* out-of-place like Fft::run (copy, then in-place transform; fft/mod.rs:45-48) */
+void yo_fft_run_f32(const yo_fft_plan *p, const cf32 *in, cf32 *out) {
+    const size_t n = p->n;
+    for (size_t i = 0; i < n; i++) out[p->rev[i]] = in[i];
+    size_t len = 1;
+    unsigned lg = 0; while (((size_t)1 << lg) < n) lg++;
+    if (lg & 1) {                          /* one radix-2 pass */
+        for (size_t i = 0; i < n; i += 2) {
+            cf32 a = out[i], b = out[i + 1];
+            out[i] = c_add(a, b); out[i + 1].re = a.re - b.re; out[i + 1].im = a.im - b.im;
+        }
+        len = 2;
+    }
+    const float sgn = p->dir ? 1.0f : -1.0f;
+    /* radix-4 passes on bit-reversed data: a radix-4 DIT butterfly over bit-reversed order
+       combines sub-blocks in order (0, 2, 1, 3) */
+    for (; len < n; len *= 4) {
+        const size_t step = n / (4 * len);
+        for (size_t blk = 0; blk < n; blk += 4 * len) {
+            for (size_t j = 0; j < len; j++) {
+                cf32 w1 = p->tw[j * step], w2 = p->tw[2 * j * step], w3 = p->tw[3 * j * step];
+                cf32 a = out[blk + j];
+                cf32 b = c_mul(out[blk + j + 2 * len], w1);   /* bit-reversed: block 1 <-> 2 */
+                cf32 c = c_mul(out[blk + j + len], w2);
+                cf32 d = c_mul(out[blk + j + 3 * len], w3);
+                cf32 t0 = c_add(a, c), t1 = { a.re - c.re, a.im - c.im };
+                cf32 t2 = c_add(b, d), t3 = { b.re - d.re, b.im - d.im };
+                /* multiply t3 by -j (forward) or +j (backward) */
+                cf32 t3r = { -sgn * t3.im, sgn * t3.re };
+                out[blk + j] = c_add(t0, t2);
+                out[blk + j + len] = c_add(t1, t3r);
+                out[blk + j + 2 * len].re = t0.re - t2.re; out[blk + j + 2 * len].im = t0.im - t2.im;
+                out[blk + j + 3 * len].re = t1.re - t3r.re; out[blk + j + 3 * len].im = t1.im - t3r.im;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Kaiser-window FIR design, all in f32 like the reference.
+ *   fir_design_kaiser                   src/filter/fir/design/kaiser.rs:16-51
+ *   kaiser_beta_stopband_attenuation    kaiser.rs:62-72
+ *   windows::kaiser                     src/math/windows.rs:76-90
+ *   besseli0f/besselif/lnbesselif       src/math/bessel.rs:9-67
+ *   lngammaf / gammaf (z>=0 branch)     src/math/gamma.rs:7-22 (+ gammaf = exp(lngammaf))
+ *   sincf                               src/math/mod.rs:63-69
+ * ---------------------------------------------------------------------------------- */
+static const float PI_F = 3.14159265358979323846f;
+
+float yo_lngammaf(float z) {
+    if (z <= 0.0f) return NAN;               /* reference panics */
+    if (z < 10.0f) return yo_lngammaf(z + 1.0f) - logf(z);
+    float g = 0.5f * (logf(2.0f * PI_F) - logf(z));
+    g += z * (logf(z + (1.0f / (12.0f * z - 0.1f / z))) - 1.0f);
+    return g;
+}
+float yo_lnbesselif(float nu, float z) {
+    if (z == 0.0f) return (nu == 0.0f) ? 0.0f : -INFINITY;
+    if (nu == 0.5f) return 0.5f * logf(2.0f / (PI_F * z)) + logf(sinhf(z));
+    if (z < 1e-3f * sqrtf(nu + 1.0f)) return -yo_lngammaf(nu + 1.0f) + nu * logf(0.5f * z);
+    float t0 = nu * logf(0.5f * z);
+    float y = 0.0f;
+    for (int k = 0; k < 64; k++) {
+        float t1 = 2.0f * (float)k * logf(0.5f * z);
+        float t2 = yo_lngammaf((float)k + 1.0f);
+        float t3 = yo_lngammaf(nu + (float)k + 1.0f);
+        y += expf(t1 - t2 - t3);
+    }
+    return t0 + logf(y);
+}
+float yo_besseli0f(float z) {
+    if (z == 0.0f) return 1.0f;
+    /* besselif(0,z): low-signal branch (0.5 z)^0 / gammaf(1) = 1 / exp(lngammaf(1)) */
+    if (z < 1e-3f) return powf(0.5f * z, 0.0f) / expf(yo_lngammaf(1.0f));
+    return expf(yo_lnbesselif(0.0f, z));
+}
+float yo_sincf(float x) {
+    if (fabsf(x) < 0.01f)
+        return cosf(PI_F * x / 2.0f) * cosf(PI_F * x / 4.0f) * cosf(PI_F * x / 8.0f);
+    return sinf(PI_F * x) / (PI_F * x);
+}
+float yo_kaiser_beta(float as_) {
+    float a = fabsf(as_);
+    if (a > 50.0f) return 0.1102f * (a - 8.7f);
+    if (a > 21.0f) return 0.5842f * powf(a - 21.0f, 0.4f) + 0.07886f * (a - 21.0f);
+    return 0.0f;
+}
+float yo_window_kaiser(size_t i, size_t wlen, float beta) {
+    float t = (float)i - (float)(wlen - 1) / 2.0f;
+    float r = 2.0f * t / (float)(wlen - 1);
+    float a = yo_besseli0f(beta * sqrtf(1.0f - r * r));
+    float b = yo_besseli0f(beta);
+    return a / b;
+}
+int yo_fir_design_kaiser(size_t n, float fc, float as_, float mu, float *h) {
+    if (mu <= -0.5f || mu > 0.5f) return YO_ECONFIG;
+    if (fc <= 0.0f || fc > 0.5f) return YO_ECONFIG;
+    if (n == 0) return YO_ECONFIG;
+    if (as_ <= 0.0f) return YO_ECONFIG;
+    float beta = yo_kaiser_beta(as_);
+    for (size_t i = 0; i < n; i++) {
+        float t = (float)i - ((float)n - 1.0f) / 2.0f + mu;
+        float h1 = yo_sincf(2.0f * fc * t);
+        float h2 = yo_window_kaiser(i, n, beta);
+        h[i] = h1 * h2;
+    }
+    return YO_OK;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Synthetic input generator: SplitMix64 used as a COUNTER-based
+ * generator (draw u = mix(seed + (u+1)*gamma)), 24-bit uniforms like rand's gen::<f32>(),
+ * Box-Muller as src/random/normal.rs:9-22 (real) and :29-44 scaled by 0.70710678 like
+ * cawgn (:46-48) so re, im ~ N(0, 1/2).  u1 is drawn from (0,1] instead of rejecting 0.
+ * ---------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+void yo_gen_real(uint64_t seed, uint64_t first, size_t n, float *x) {
+    for (size_t i = 0; i < n; i++) {
+        uint64_t a = splitmix64_at(seed, 2 * (first + i)), b = splitmix64_at(seed, 2 * (first + i) + 1);
+        float u1 = (float)((a >> 40) + 1) * (1.0f / 16777216.0f);
+        float u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+        x[i] = sqrtf(-2.0f * logf(u1)) * sinf(2.0f * PI_F * u2);
+    }
+}
+void yo_gen_complex(uint64_t seed, uint64_t first, size_t n, cf32 *x) {
+    for (size_t i = 0; i < n; i++) {
+        uint64_t a = splitmix64_at(seed, 2 * (first + i)), b = splitmix64_at(seed, 2 * (first + i) + 1);
+        float u1 = (float)((a >> 40) + 1) * (1.0f / 16777216.0f);
+        float u2 = (float)(b >> 40) * (1.0f / 16777216.0f);
+        float r = sqrtf(-2.0f * logf(u1)) * 0.70710678f, th = 2.0f * PI_F * u2;
+        x[i].re = r * cosf(th); x[i].im = r * sinf(th);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * firpfbch / firpfbch2 analyzers -- NOT IN THE REFERENCE (multichannel/mod.rs is empty).
+ * PARITY UNPINNED.  Composed from the reference's primitives with liquid-dsp's published
+ * conventions (the library yagi rewrites; LIQUID_COMPAT.md:1765-1798 lists the absent
+ * autotests):
+ *   firpfbch analyzer, M channels, p taps per branch, prototype h[0..p*M):
+ *     branch i taps h_sub[n] = h[i + n*M] stored reversed (exactly FirPfbFilter, firpfb.rs:45-52),
+ *     one Window of length p per branch; push(x): w[idx].push(x); idx = (idx+M-1)%M, idx0 = M-1;
+ *     run: X[M-1-i] = dot(branch_i, w[i]); y = forward DFT_M(X).  One frame = M pushes + run.
+ *   firpfbch2 analyzer (2x oversampled), M even, m: h_len = 2*M*m, branch length 2m,
+ *     one Window per branch; each step consumes M/2 inputs x[i] -> w[base-1-i], base = flag?M:M/2;
+ *     X[b(i)] = dot(branch_i, w[b(i)]) with b(i) = (i + (flag ? M/2 : 0)) % M;
+ *     y = IDFT_M(X)/M (unnormalised backward DFT then divide); flag ^= 1.
+ * The DFT here is the f64 definition rounded to f32 at the end; branch dots are f32
+ * sequential like dotprod.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { size_t M, p, idx; float *filt; yo_window **w; } yo_firpfbch;
+
+yo_firpfbch *yo_firpfbch_create(size_t M, size_t p, const float *h) {
+    if (M == 0 || p == 0) return NULL;
+    yo_firpfbch *q = (yo_firpfbch *)calloc(1, sizeof(*q));
+    q->M = M; q->p = p; q->idx = M - 1;
+    q->filt = (float *)malloc(M * p * sizeof(float));
+    q->w = (yo_window **)malloc(M * sizeof(yo_window *));
+    for (size_t i = 0; i < M; i++) {
+        for (size_t n = 0; n < p; n++) q->filt[i * p + (p - n - 1)] = h[i + n * M];
+        q->w[i] = yo_window_create(p, sizeof(cf32));
+    }
+    return q;
+}
+void yo_firpfbch_destroy(yo_firpfbch *q) {
+    if (!q) return;
+    for (size_t i = 0; i < q->M; i++) yo_window_destroy(q->w[i]);
+    free(q->w); free(q->filt); free(q);
+}
+/* x: nframes*M inputs; y: nframes*M outputs [frame][channel] */
+void yo_firpfbch_analyzer_execute(yo_firpfbch *q, const cf32 *x, size_t nframes, cf32 *y) {
+    const size_t M = q->M, p = q->p;
+    cf32 *X = (cf32 *)malloc(M * sizeof(cf32));
+    cf64 *Y = (cf64 *)malloc(M * sizeof(cf64));
+    for (size_t f = 0; f < nframes; f++) {
+        for (size_t i = 0; i < M; i++) {
+            yo_window_push(q->w[q->idx], &x[f * M + i]);
+            q->idx = (q->idx + M - 1) % M;
+        }
+        for (size_t i = 0; i < M; i++) {
+            const cf32 *r = (const cf32 *)yo_window_read(q->w[i]);
+            yo_dotprod_rcc(q->filt + i * p, r, p, &X[M - 1 - i]);
+        }
+        yo_dft_f64(X, M, 0, Y);
+        for (size_t k = 0; k < M; k++) { y[f * M + k].re = (float)Y[k].re; y[f * M + k].im = (float)Y[k].im; }
+    }
+    free(X); free(Y);
+}
+
+typedef struct { size_t M, m, flag; float *filt; yo_window **w; } yo_firpfbch2;
+
+yo_firpfbch2 *yo_firpfbch2_create(size_t M, size_t m, const float *h) {
+    if (M < 2 || (M & 1) || m < 1) return NULL;
+    yo_firpfbch2 *q = (yo_firpfbch2 *)calloc(1, sizeof(*q));
+    const size_t p = 2 * m;
+    q->M = M; q->m = m; q->flag = 0;
+    q->filt = (float *)malloc(M * p * sizeof(float));
+    q->w = (yo_window **)malloc(M * sizeof(yo_window *));
+    for (size_t i = 0; i < M; i++) {
+        for (size_t n = 0; n < p; n++) q->filt[i * p + (p - n - 1)] = h[i + n * M];
+        q->w[i] = yo_window_create(p, sizeof(cf32));
+    }
+    return q;
+}
+void yo_firpfbch2_destroy(yo_firpfbch2 *q) {
+    if (!q) return;
+    for (size_t i = 0; i < q->M; i++) yo_window_destroy(q->w[i]);
+    free(q->w); free(q->filt); free(q);
+}
+/* x: nsteps*(M/2) inputs; y: nsteps*M outputs [step][channel] */
+void yo_firpfbch2_analyzer_execute(yo_firpfbch2 *q, const cf32 *x, size_t nsteps, cf32 *y) {
+    const size_t M = q->M, M2 = M / 2, p = 2 * q->m;
+    cf32 *X = (cf32 *)malloc(M * sizeof(cf32));
+    cf64 *Y = (cf64 *)malloc(M * sizeof(cf64));
+    for (size_t s = 0; s < nsteps; s++) {
+        size_t base = q->flag ? M : M2;
+        for (size_t i = 0; i < M2; i++) yo_window_push(q->w[base - i - 1], &x[s * M2 + i]);
+        size_t offset = q->flag ? M2 : 0;
+        for (size_t i = 0; i < M; i++) {
+            size_t b = (offset + i) % M;           /* window index and IDFT input slot */
+            const cf32 *r = (const cf32 *)yo_window_read(q->w[b]);
+            yo_dotprod_rcc(q->filt + i * p, r, p, &X[b]);
+        }
+        yo_dft_f64(X, M, 1, Y);
+        for (size_t k = 0; k < M; k++) {
+            y[s * M + k].re = (float)(Y[k].re / (double)M);
+            y[s * M + k].im = (float)(Y[k].im / (double)M);
+        }
+        q->flag = 1 - q->flag;
+    }
+    free(X); free(Y);
+}
+
+/* the headline stream: firfilt_crcf execute_block, output cut into
+ * consecutive nfft-sample frames, forward FFT of each (f32 radix-4 plan above).
+ * Used by tests (small) and as the timed cpu_baseline of bench.py. */
+void yo_stream_fir_fft(yo_firfilt_crcf *q, const yo_fft_plan *p, const cf32 *x, size_t nframes,
+                       cf32 *scratch, cf32 *spectra) {
+    const size_t n = p->n;
+    for (size_t f = 0; f < nframes; f++) {
+        yo_firfilt_crcf_execute_block(q, x + f * n, n, scratch, n);
+        yo_fft_run_f32(p, scratch, spectra + f * n);
+    }
+}
