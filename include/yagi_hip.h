@@ -1,0 +1,289 @@
+/*
+ * yagi_hip.h -- C ABI of libyagi_hip.so: the MI355X (gfx950) FIR/FFT engine that sits behind
+ * yagi's `new / push / execute / execute_block` object API.
+ *
+ * yagi (EEGKit/yagi, Rust) has no FFI of its own for this path; its only C-ABI precedent is the
+ * stub `c_shim` (c_shim/src/lib.rs:3-12: opaque `*mut foo_s` handle, `c_uint` sizes, `c_int`
+ * status).  The entry points below are what a `hip` feature of yagi would bind with
+ * `extern "C"` (see INTEGRATION.md for the Rust side).  Every group cites the reference item
+ * (file:line, relative to the reference root) whose behaviour it reproduces.
+ *
+ * Conventions
+ *   - Complex samples are `yagi_cf32` = `num_complex::Complex<f32>` (#[repr(C)] {re, im}).
+ *   - Type suffixes follow liquid-dsp / yagi's test names:
+ *       rrrf = FirFilter<f32, f32>, crcf = FirFilter<Complex32, f32>,
+ *       cccf = FirFilter<Complex32, Complex32>   (T = sample/output type, C = Coeff type).
+ *   - Every function returns a yagi_status (0 = OK).  The variants mirror error::Error
+ *     (src/error.rs:7-14); YAGI_ERR_DEVICE is added for HIP/RCCL failures.  Where the reference
+ *     panics on a slice index (firdecim.rs:182, dotprod/mod.rs:104, fft/mod.rs:46) this library
+ *     returns YAGI_ERR_CONFIG instead of aborting.  yagi_hip_last_error() gives the message
+ *     (thread-local), like the String each Error variant carries.
+ *   - Pointers are HOST pointers unless the function name ends in `_dev`, in which case data
+ *     pointers are device (HBM) pointers and the call is asynchronous on the handle's stream.
+ *   - A handle owns its device taps, its device window (the filter state), a workspace and a
+ *     stream reference.  One handle = one owner thread at a time (the reference's `&mut self`);
+ *     distinct handles may be used concurrently.  Fft plans are read-only once created.
+ *   - There is NO CPU fallback: every arithmetic result is produced by a HIP kernel; if no
+ *     device is present the first call fails with YAGI_ERR_DEVICE.
+ */
+#ifndef YAGI_HIP_H
+#define YAGI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } yagi_cf32;
+
+typedef enum {
+    YAGI_OK = 0,
+    YAGI_ERR_INTERNAL = 1,        /* Error::Internal       error.rs:8  */
+    YAGI_ERR_CONFIG = 2,          /* Error::Config         error.rs:9  */
+    YAGI_ERR_VALUE = 3,           /* Error::Value          error.rs:10 */
+    YAGI_ERR_RANGE = 4,           /* Error::Range          error.rs:11 */
+    YAGI_ERR_MODE = 5,            /* Error::Mode           error.rs:12 */
+    YAGI_ERR_NO_CONVERGENCE = 6,  /* Error::NoConvergence  error.rs:13 */
+    YAGI_ERR_DEVICE = 7           /* HIP / RCCL failure (no reference counterpart) */
+} yagi_status;
+
+typedef void *yagi_stream_t;      /* a hipStream_t; NULL = the default stream */
+
+/* fft::Direction (src/fft/mod.rs:13-17) */
+#define YAGI_FFT_FORWARD 0
+#define YAGI_FFT_BACKWARD 1
+
+const char *yagi_hip_last_error(void);
+const char *yagi_hip_version(void);
+
+/* ---- device plumbing (no reference counterpart: the reference has no device boundary) ---- */
+int yagi_hip_device_count(int *count);
+int yagi_hip_set_device(int device);
+int yagi_hip_malloc(void **dev_ptr, size_t bytes);
+int yagi_hip_free(void *dev_ptr);
+int yagi_hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int yagi_hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int yagi_hip_memset_dev(void *dst_dev, int value, size_t bytes);
+int yagi_hip_device_synchronize(void);
+int yagi_hip_stream_synchronize(yagi_stream_t stream);
+
+/* Synthetic input: counter-based SplitMix64 + Box-Muller in the shape of
+ * random::randnf / crandnf (src/random/normal.rs:9-44); sample i of a stream depends only on
+ * (seed, first + i).  Complex samples have re, im ~ N(0, 1/2). */
+int yagi_hip_gen_real_dev(uint64_t seed, uint64_t first, size_t n, float *x_dev, yagi_stream_t s);
+int yagi_hip_gen_complex_dev(uint64_t seed, uint64_t first, size_t n, yagi_cf32 *x_dev, yagi_stream_t s);
+
+/* ---- dotprod: trait DotProd (src/dotprod/mod.rs:13-73) -----------------------------------
+ *   rrrf: [f32].[f32]            mod.rs:19-31      rccf: [f32].[Complex]      mod.rs:33-45
+ *   crcf: [Complex].[f32]        mod.rs:47-59      cccf: [Complex].[Complex]  mod.rs:61-73
+ * y = sum_i a[i]*b[i] over n = the common length.  Kernel: per-lane strided FMA, wave64
+ * shuffle tree, LDS cross-wave, fixed-order two-pass combine (bitwise reproducible). */
+int yagi_hip_dotprod_rrrf(const float *a, const float *b, size_t n, float *y);
+int yagi_hip_dotprod_rccf(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y);
+int yagi_hip_dotprod_crcf(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y);
+int yagi_hip_dotprod_cccf(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y);
+int yagi_hip_dotprod_rrrf_dev(const float *a, const float *b, size_t n, float *y, yagi_stream_t s);
+int yagi_hip_dotprod_rccf_dev(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s);
+int yagi_hip_dotprod_crcf_dev(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y, yagi_stream_t s);
+int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s);
+
+/* ---- FIR objects --------------------------------------------------------------------------
+ * YAGI_FIR_API(K, T, C) declares, for type combination K:
+ *
+ * firfilt  = FirFilter<T,C>             src/filter/fir/firfilt.rs
+ *   create              new(h)                          :63-79   (h_len == 0 -> CONFIG)
+ *   create_kaiser       new_kaiser(n, fc, as_, mu)      :93-97   (design: kaiser.rs:16-51)
+ *   create_rect         new_rect(n)                     :149-155 (n in [1,1024])
+ *   clone               #[derive(Clone)]                :8       (state continues identically)
+ *   set_coefficients    set_coefficients(h) (+reset)    :193-206
+ *   reset               reset()                         :209-213
+ *   push / write        push(x) / write(&[x])           :220-234
+ *   execute             execute() -> T                  :241-246 (dotprod kernel on the window)
+ *   execute_one         execute_one(x)                  :256-259
+ *   execute_block       execute_block(x, y)             :267-278 (nx != ny -> CONFIG)
+ *   set_scale/get_scale/get_length/get_coefficients      :285-314
+ *   y[i] = scale * sum_{k<L} h[k] * x[i-k], history zero at start.
+ *
+ * firdecim = FirDecimationFilter<T,C>   src/filter/fir/firdecim.rs
+ *   create              new(M, h, h_len)                :38-57   (h_len==0 or M==0 -> CONFIG)
+ *   create_kaiser       new_kaiser(M, m, as_)           :70-87   (M<2, m==0, as_<0 -> CONFIG)
+ *   execute             execute(&x[..M]) -> T           :179-191
+ *   execute_block       execute_block(x, n, y)          :200-205 (x holds n*M samples)
+ *   y[i] = scale * sum_k h[k] * x[i*M - k].
+ *
+ * firpfb   = FirPfbFilter<T,C>          src/filter/fir/firpfb.rs
+ *   create              new(num_filters, h, h_len)      :34-65   (h_sub_len = h_len / num_filters)
+ *   create_kaiser       new_kaiser(M, m, fc, as_)       :94-114
+ *   create_default      default(M, m)                   :79-81
+ *   push / write / execute(i) / execute_block(i, x, y)  :255-301 (i >= num_filters -> CONFIG)
+ *   execute_all_dev     all num_filters branch outputs for every pushed sample (polyphase
+ *                       interpolator form, firinterp.rs:224-231): y[n][i], n-major
+ *   execute_select_dev  branch index per sample (the access pattern of resamp.rs:141-154)
+ *   y_i[n] = scale * sum_k h[i + k*M] * x[n-k].
+ *
+ * `_dev` variants take device pointers and run asynchronously on the handle's stream.
+ */
+#define YAGI_FIR_API(K, T, C)                                                                       \
+    typedef struct yagi_hip_firfilt_##K##_s *yagi_hip_firfilt_##K;                                  \
+    int yagi_hip_firfilt_##K##_create(const C *h, size_t h_len, yagi_hip_firfilt_##K *q);           \
+    int yagi_hip_firfilt_##K##_create_kaiser(size_t n, float fc, float as_, float mu,               \
+                                             yagi_hip_firfilt_##K *q);                              \
+    int yagi_hip_firfilt_##K##_create_rect(size_t n, yagi_hip_firfilt_##K *q);                      \
+    int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q);                                     \
+    int yagi_hip_firfilt_##K##_clone(yagi_hip_firfilt_##K q, yagi_hip_firfilt_##K *out);            \
+    int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s);                 \
+    int yagi_hip_firfilt_##K##_set_coefficients(yagi_hip_firfilt_##K q, const C *h, size_t h_len);  \
+    int yagi_hip_firfilt_##K##_reset(yagi_hip_firfilt_##K q);                                       \
+    int yagi_hip_firfilt_##K##_push(yagi_hip_firfilt_##K q, T x);                                   \
+    int yagi_hip_firfilt_##K##_write(yagi_hip_firfilt_##K q, const T *x, size_t n);                 \
+    int yagi_hip_firfilt_##K##_execute(yagi_hip_firfilt_##K q, T *y);                               \
+    int yagi_hip_firfilt_##K##_execute_one(yagi_hip_firfilt_##K q, T x, T *y);                      \
+    int yagi_hip_firfilt_##K##_execute_block(yagi_hip_firfilt_##K q, const T *x, size_t nx, T *y,   \
+                                             size_t ny);                                            \
+    int yagi_hip_firfilt_##K##_execute_block_dev(yagi_hip_firfilt_##K q, const T *x_dev, size_t n,  \
+                                                 T *y_dev);                                         \
+    int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C scale);                          \
+    int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *scale);                         \
+    int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *h_len);                   \
+    int yagi_hip_firfilt_##K##_get_coefficients(yagi_hip_firfilt_##K q, C *h, size_t h_len);        \
+                                                                                                    \
+    typedef struct yagi_hip_firdecim_##K##_s *yagi_hip_firdecim_##K;                                \
+    int yagi_hip_firdecim_##K##_create(size_t M, const C *h, size_t h_len,                          \
+                                       yagi_hip_firdecim_##K *q);                                   \
+    int yagi_hip_firdecim_##K##_create_kaiser(size_t M, size_t m, float as_,                        \
+                                              yagi_hip_firdecim_##K *q);                            \
+    int yagi_hip_firdecim_##K##_destroy(yagi_hip_firdecim_##K q);                                   \
+    int yagi_hip_firdecim_##K##_clone(yagi_hip_firdecim_##K q, yagi_hip_firdecim_##K *out);         \
+    int yagi_hip_firdecim_##K##_set_stream(yagi_hip_firdecim_##K q, yagi_stream_t s);               \
+    int yagi_hip_firdecim_##K##_reset(yagi_hip_firdecim_##K q);                                     \
+    int yagi_hip_firdecim_##K##_get_decim_rate(yagi_hip_firdecim_##K q, size_t *M);                 \
+    int yagi_hip_firdecim_##K##_set_scale(yagi_hip_firdecim_##K q, C scale);                        \
+    int yagi_hip_firdecim_##K##_get_scale(yagi_hip_firdecim_##K q, C *scale);                       \
+    int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y);      \
+    int yagi_hip_firdecim_##K##_execute_block(yagi_hip_firdecim_##K q, const T *x, size_t nx,       \
+                                              size_t n, T *y);                                      \
+    int yagi_hip_firdecim_##K##_execute_block_dev(yagi_hip_firdecim_##K q, const T *x_dev,          \
+                                                  size_t n, T *y_dev);                              \
+                                                                                                    \
+    typedef struct yagi_hip_firpfb_##K##_s *yagi_hip_firpfb_##K;                                    \
+    int yagi_hip_firpfb_##K##_create(size_t num_filters, const C *h, size_t h_len,                  \
+                                     yagi_hip_firpfb_##K *q);                                       \
+    int yagi_hip_firpfb_##K##_create_kaiser(size_t num_filters, size_t m, float fc, float as_,      \
+                                            yagi_hip_firpfb_##K *q);                                \
+    int yagi_hip_firpfb_##K##_create_default(size_t num_filters, size_t m,                          \
+                                             yagi_hip_firpfb_##K *q);                               \
+    int yagi_hip_firpfb_##K##_destroy(yagi_hip_firpfb_##K q);                                       \
+    int yagi_hip_firpfb_##K##_clone(yagi_hip_firpfb_##K q, yagi_hip_firpfb_##K *out);               \
+    int yagi_hip_firpfb_##K##_set_stream(yagi_hip_firpfb_##K q, yagi_stream_t s);                   \
+    int yagi_hip_firpfb_##K##_reset(yagi_hip_firpfb_##K q);                                         \
+    int yagi_hip_firpfb_##K##_set_scale(yagi_hip_firpfb_##K q, C scale);                            \
+    int yagi_hip_firpfb_##K##_get_scale(yagi_hip_firpfb_##K q, C *scale);                           \
+    int yagi_hip_firpfb_##K##_push(yagi_hip_firpfb_##K q, T x);                                     \
+    int yagi_hip_firpfb_##K##_write(yagi_hip_firpfb_##K q, const T *x, size_t n);                   \
+    int yagi_hip_firpfb_##K##_execute(yagi_hip_firpfb_##K q, size_t i, T *y);                       \
+    int yagi_hip_firpfb_##K##_execute_block(yagi_hip_firpfb_##K q, size_t i, const T *x,            \
+                                            size_t nx, T *y, size_t ny);                            \
+    int yagi_hip_firpfb_##K##_execute_block_dev(yagi_hip_firpfb_##K q, size_t i, const T *x_dev,    \
+                                                size_t n, T *y_dev);                                \
+    int yagi_hip_firpfb_##K##_execute_all_dev(yagi_hip_firpfb_##K q, const T *x_dev, size_t n,      \
+                                              T *y_dev);                                            \
+    int yagi_hip_firpfb_##K##_execute_select_dev(yagi_hip_firpfb_##K q, const uint32_t *idx_dev,    \
+                                                 const T *x_dev, size_t n, T *y_dev);
+
+YAGI_FIR_API(rrrf, float, float)
+YAGI_FIR_API(crcf, yagi_cf32, float)
+YAGI_FIR_API(cccf, yagi_cf32, yagi_cf32)
+
+/* crcf only: which block kernel execute_block uses.  0 = auto, 1 = general LDS-broadcast kernel
+ * (fir_kernels.hip), 2 = register-sliding kernel (stream_kernels.hip).  Test / ablation knob. */
+int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);
+
+/* ---- Fft<f32>: src/fft/mod.rs:33-69 (arithmetic = rustfft 6.2 in the reference) ------------
+ *   create       Fft::new(n, direction)        :39-43   any n >= 1 the engine supports
+ *   run          run(input, output)            :45-48   out of place, unnormalised,
+ *                                                       forward = e^{-j 2 pi n k / N}
+ *   run_batch_dev  `batch` contiguous transforms, device pointers (config C3)
+ *   shift        shift(input, n)               :50-57   swap halves (odd n: last stays)
+ *   fft_run      fft_run(input, output, dir)   :66-69   plan + run in one call
+ * Sizes: any n whose largest prime factor p satisfies n <= 8192 (single-kernel LDS path), plus
+ * Bluestein for n <= 4096 with a prime factor > 64; unsupported sizes return CONFIG.        */
+typedef struct yagi_hip_fft_s *yagi_hip_fft;
+int yagi_hip_fft_create(size_t n, int direction, yagi_hip_fft *plan);
+int yagi_hip_fft_destroy(yagi_hip_fft plan);
+int yagi_hip_fft_clone(yagi_hip_fft plan, yagi_hip_fft *out);
+int yagi_hip_fft_len(yagi_hip_fft plan, size_t *n);
+int yagi_hip_fft_run(yagi_hip_fft plan, const yagi_cf32 *input, size_t n_in, yagi_cf32 *output,
+                     size_t n_out);
+int yagi_hip_fft_run_batch_dev(yagi_hip_fft plan, const yagi_cf32 *in_dev, yagi_cf32 *out_dev,
+                               size_t batch, yagi_stream_t s);
+int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n);
+int yagi_hip_fft_shift_dev(yagi_cf32 *buf_dev, size_t n, size_t batch, yagi_stream_t s);
+int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n, int direction);
+
+/* ---- the headline stream: FirFilter<Complex32,f32>::execute_block
+ * (firfilt.rs:267-278) feeding consecutive nfft-sample frames to Fft::run forward
+ * (fft/mod.rs:45-48), fused so the FIR output never touches HBM.  nfft = 4096 (fused kernel);
+ * filter state carries across calls exactly like the FirFilter object's. */
+typedef struct yagi_hip_firfft_crcf_s *yagi_hip_firfft_crcf;
+int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_hip_firfft_crcf *q);
+int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q);
+int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s);
+int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale);
+int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q);
+/* variant: 0 = auto, 1 = LDS-broadcast VALU FIR, 2 = MFMA Toeplitz FIR (bench/ablation knob) */
+int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant);
+int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes,
+                                 yagi_cf32 *spectra);
+int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x_dev,
+                                     size_t nframes, yagi_cf32 *spectra_dev);
+
+/* ---- multichannel::firpfbch / firpfbch2 analyzers ------------------------------------------
+ * ABSENT from the reference (src/multichannel/mod.rs is 0 lines; LIQUID_COMPAT.md:1765-1798).
+ * Semantics are liquid-dsp's (the library yagi rewrites), composed from the reference's own
+ * primitives: FirPfb-style branch split (firpfb.rs:45-52), Window (window.rs), dotprod, Fft.
+ *   firpfbch  analyzer: M channels, p taps/branch, prototype h[0 .. p*M); one frame = M input
+ *             samples -> M channel outputs: X[M-1-i] = branch_i . window_i ; y = DFT_M(X).
+ *             create_kaiser(M, m, as_): h = kaiser(2*M*m+1, 0.5/M, as_), p = 2*m.
+ *   firpfbch2 analyzer (2x oversampled): M even, branch length 2*m, h[0 .. 2*M*m); one step =
+ *             M/2 inputs -> M outputs, alternating half rotation, y = IDFT_M(X)/M.
+ *             create_kaiser(M, m, as_): h = kaiser(2*M*m+1, 1/M, as_) * M / sum(h).
+ * Output layout [frame][channel].  The `_shard_dev` form computes only the sub-bands
+ * k = rank + nranks*q (q < M/nranks) into yshard[step][q] so an 8-GPU node can all-gather them
+ * (RCCL) -- see INTEGRATION.md; `assemble_dev` permutes the gathered [rank][step][q] slabs into
+ * [step][channel]. */
+typedef struct yagi_hip_firpfbch_crcf_s *yagi_hip_firpfbch_crcf;
+int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_firpfbch_crcf *q);
+int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch_crcf *q);
+int yagi_hip_firpfbch_crcf_destroy(yagi_hip_firpfbch_crcf q);
+int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s);
+int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q);
+int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x,
+                                            size_t nframes, yagi_cf32 *y);
+int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x_dev,
+                                                size_t nframes, yagi_cf32 *y_dev);
+
+typedef struct yagi_hip_firpfbch2_crcf_s *yagi_hip_firpfbch2_crcf;
+int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q);
+int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q);
+int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q);
+int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s);
+int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q);
+int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x,
+                                             size_t nsteps, yagi_cf32 *y);
+int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x_dev,
+                                                 size_t nsteps, yagi_cf32 *y_dev);
+int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q,
+                                                       const yagi_cf32 *x_dev, size_t nsteps,
+                                                       int rank, int nranks, yagi_cf32 *yshard_dev);
+int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered_dev, size_t nsteps, size_t M,
+                                         int nranks, yagi_cf32 *y_dev, yagi_stream_t s);
+
+/* ---- design helper exposed for hosts that want the taps (kaiser.rs:16-51) ---------------- */
+int yagi_hip_fir_design_kaiser(size_t n, float fc, float as_, float mu, float *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAGI_HIP_H */

@@ -123,3 +123,11 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- fft4096.npz is NOT transcribed from the reference (it holds no vector above N = 509):
+# it is 4 transforms of the C3 stream, input from the oracle's generator (seed 0x59414749+3) and
+# output from numpy's f64 FFT, written by:
+#   x = oracle.gen_complex(0x59414749 + 3, 4 * 4096)
+#   y = [numpy.fft.fft(x[b*4096:(b+1)*4096].astype(complex128)) for b in range(4)]
+#   numpy.savez_compressed("tests/golden/fft4096.npz", x=x, y=y)

@@ -1,0 +1,136 @@
+"""firpfbch / firpfbch2 analyzers through the C ABI vs the oracle restatement + property tests.
+PARITY UNPINNED by the reference (src/multichannel/mod.rs is empty): the conventions are
+liquid-dsp's and are pinned here by (1) tone in channel k -> output k only, (2) channel-0 impulse
+response = decimated prototype, (3) M-channel analyzer == M parallel firdecim branches,
+(4) sharded sub-bands + assemble == unsharded."""
+import numpy as np
+import pytest
+
+from gpu_util import SEED, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yagi_amd
+    assert yagi_amd.device_count() > 0
+    return yagi_amd
+
+
+@pytest.mark.parametrize("M,m", [(4, 2), (8, 4), (64, 8), (6, 3), (10, 2), (256, 4), (1, 3)])
+def test_firpfbch_vs_oracle(ya, oracle, M, m):
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0) if M > 1 else np.float32([0.1, 0.5, 0.3, 0.2, 0.1, 0.05, 0.0])
+    nfr = 150
+    x = oracle.gen_complex(SEED + 4, nfr * M)
+    ref = oracle.FirPfbCh(M, 2 * m, h)
+    want = ref.analyzer_execute(x)
+    q = ya.FirPfbCh(M, 2 * m, h)
+    got = np.concatenate([q.analyzer_execute(x[: 37 * M]), q.analyzer_execute(x[37 * M:])])
+    assert rel_l2(got, want) <= 2e-6
+    q.reset()
+    assert rel_l2(q.analyzer_execute(x[: 5 * M]), want[:5]) <= 2e-6
+
+
+def test_firpfbch_kaiser_ctor_and_tone(ya, oracle):
+    M, m = 64, 8
+    q = ya.FirPfbCh.new_kaiser(M, m, 60.0)
+    n = np.arange(M * 96)
+    for k in (0, 1, 31, 32, 63):
+        q.reset()
+        y = q.analyzer_execute(np.exp(2j * np.pi * k / M * n).astype(np.complex64))[-1]
+        p = 20 * np.log10(np.abs(y) / np.max(np.abs(y)) + 1e-12)
+        assert np.argmax(p) == k
+        assert np.all(np.delete(p, k) <= -55.0)
+
+
+def test_firpfbch_equals_firdecim_per_channel(ya, oracle):
+    """channel k of the analyzer == mix down by k/M, lowpass with the prototype, keep 1 of M
+    (up to the polyphase phase convention: y_k[f] uses input up to sample f*M + M-1)."""
+    M, m = 8, 3
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)[: 2 * M * m]
+    nfr = 64
+    x = oracle.gen_complex(SEED + 4, nfr * M)
+    got = ya.FirPfbCh(M, 2 * m, h).analyzer_execute(x)
+    n = np.arange(nfr * M)
+    for k in range(M):
+        mixed = x.astype(np.complex128) * np.exp(-2j * np.pi * k * n / M)
+        full = np.convolve(mixed, h.astype(np.float64))[: nfr * M]
+        want = full[M - 1:: M] * np.exp(2j * np.pi * k * (M - 1) / M)      # newest sample = f*M + M-1
+        assert rel_l2(got[:, k], want) <= 1e-5, k
+
+
+@pytest.mark.parametrize("M,m", [(4, 2), (8, 4), (64, 3), (256, 4), (6, 2), (10, 1)])
+def test_firpfbch2_vs_oracle(ya, oracle, M, m):
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
+    h = (h * M / h.sum()).astype(np.float32)
+    ns = 201
+    x = oracle.gen_complex(SEED + 5, ns * (M // 2))
+    want = oracle.FirPfbCh2(M, m, h).analyzer_execute(x)
+    q = ya.FirPfbCh2(M, m, h)
+    M2 = M // 2
+    got = np.concatenate([q.analyzer_execute(x[: 33 * M2]), q.analyzer_execute(x[33 * M2: 34 * M2]),
+                          q.analyzer_execute(x[34 * M2:])])           # odd split: parity carried
+    assert rel_l2(got, want) <= 2e-6
+    q.reset()
+    assert rel_l2(q.analyzer_execute(x[: 9 * M2]), want[:9]) <= 2e-6
+
+
+def test_firpfbch2_kaiser_tone_unit_gain(ya):
+    M, m = 256, 4
+    q = ya.FirPfbCh2.new_kaiser(M, m, 60.0)
+    n = np.arange((M // 2) * 64)
+    for k in (0, 3, 128, 255):
+        q.reset()
+        y = q.analyzer_execute(np.exp(2j * np.pi * k / M * n).astype(np.complex64))
+        p = np.abs(y[-1])
+        assert np.argmax(p) == k and abs(p[k] - 1.0) < 1e-3
+        far = np.ones(M, bool)
+        far[[(k - 1) % M, k, (k + 1) % M]] = False
+        assert 20 * np.log10(np.max(p[far]) + 1e-12) <= -55.0
+        assert abs(np.angle(y[-1][k] / y[-2][k])) < 1e-3        # channel-centre tone -> DC in both phases
+
+
+@pytest.mark.parametrize("M,R", [(256, 8), (256, 2), (64, 4), (8, 8), (12, 3)])
+def test_firpfbch2_sharded_equals_unsharded(ya, oracle, M, R):
+    """config C5's partitioning: rank r computes sub-bands k = r + R*q; assembling the R shards
+    (what the RCCL all-gather + assemble kernel produce) reproduces the full analyzer."""
+    m = 4
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
+    h = (h * M / h.sum()).astype(np.float32)
+    ns = 96
+    x = oracle.gen_complex(SEED + 5, ns * (M // 2))
+    full = ya.FirPfbCh2(M, m, h).analyzer_execute(x)
+    dx = ya.DeviceArray.from_numpy(x)
+    gathered = ya.DeviceArray(ns * M, np.complex64)          # [rank][step][M/R]
+    Mr = M // R
+    for r in range(R):
+        q = ya.FirPfbCh2(M, m, h)
+        shard = ya.DeviceArray(ns * Mr, np.complex64)
+        q.analyzer_execute_shard_dev(dx, 40, r, R, shard)                       # two calls: state carried
+        q.analyzer_execute_shard_dev(dx.ptr + 40 * (M // 2) * 8, ns - 40, r, R, shard.ptr + 40 * Mr * 8)
+        ya.synchronize()
+        s = shard.to_numpy().reshape(ns, Mr)
+        assert rel_l2(s, full[:, r::R]) <= 2e-6, r
+        ya.lib.yagi_hip_memcpy_h2d(gathered.ptr + r * ns * Mr * 8, s.ctypes.data, s.nbytes)
+    out = ya.DeviceArray(ns * M, np.complex64)
+    ya.FirPfbCh2.assemble_dev(gathered, ns, M, R, out)
+    ya.synchronize()
+    assert rel_l2(out.to_numpy().reshape(ns, M), full) <= 2e-6
+
+
+def test_chan_config(ya):
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbCh.new_kaiser(0, 4, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbCh.new_kaiser(8, 0, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbCh2.new_kaiser(7, 4, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbCh2.new_kaiser(8, 0, 60.0)
+    q = ya.FirPfbCh2.new_kaiser(8, 2, 60.0)
+    with pytest.raises(ya.ConfigError):
+        q.analyzer_execute(np.zeros(7, np.complex64))
+    d = ya.DeviceArray(64, np.complex64)
+    with pytest.raises(ya.ConfigError):
+        q.analyzer_execute_shard_dev(d, 4, 0, 3, d)        # 8 channels do not shard 3 ways

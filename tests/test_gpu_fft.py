@@ -1,0 +1,122 @@
+"""HIP FFT through the C ABI vs the f64 DFT definition and the reference's 33 golden sizes
+(src/fft/mod.rs:77-352; abs tol 2e-4 forward and on the inverse round trip)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from gpu_util import SEED, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FFT_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 16, 17, 20, 21, 22, 24, 26, 30, 32, 35, 36, 43, 48, 63, 64,
+             79, 92, 96, 120, 130, 157, 192, 317, 509]
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yagi_amd
+    assert yagi_amd.device_count() > 0
+    return yagi_amd
+
+
+@pytest.mark.parametrize("n", FFT_SIZES)
+def test_fft_golden(ya, n):
+    g = load_golden("fft")
+    x, test = g[f"fft_test_x{n}"], g[f"fft_test_y{n}"]
+    fwd = ya.Fft(n, ya.Direction.Forward)
+    bwd = ya.Fft(n, ya.Direction.Backward)
+    y = fwd.run(x)
+    z = bwd.run(y) / np.float32(n)
+    assert np.max(np.abs(y - test)) <= 2e-4
+    assert np.max(np.abs(z - x)) <= 2e-4
+    assert np.max(np.abs(ya.fft_run(x, ya.Direction.Forward) - test)) <= 2e-4
+
+
+def test_fft_shift(ya):
+    """fft/mod.rs:77-123 (+ odd n: last element stays, :51)"""
+    f = ya.Fft(4, ya.Direction.Forward)
+    for n, want in [(4, [2, 3, 0, 1]), (8, [4, 5, 6, 7, 0, 1, 2, 3]), (5, [2, 3, 0, 1, 4]), (1, [0])]:
+        v = (np.arange(n) * (1 + 1j)).astype(np.complex64)
+        assert np.array_equal(f.shift(v, n), (np.array(want) * (1 + 1j)).astype(np.complex64))
+
+
+def test_fft_config(ya):
+    with pytest.raises(ya.ConfigError):
+        ya.Fft(0, ya.Direction.Forward)
+    with pytest.raises(ya.ConfigError):
+        ya.Fft(1 << 20, ya.Direction.Forward)          # documented size limit
+    f = ya.Fft(16, ya.Direction.Forward)
+    with pytest.raises(ya.ConfigError):                # the reference panics (copy_from_slice)
+        f.run(np.zeros(15, np.complex64))
+    assert np.array_equal(ya.Fft(1, ya.Direction.Forward).run(np.complex64([3 - 2j])), np.complex64([3 - 2j]))
+
+
+@pytest.mark.parametrize("n", [64, 256, 1000, 1024, 2048, 3125, 4096, 8192, 4093])
+@pytest.mark.parametrize("direction", ["Forward", "Backward"])
+def test_fft_vs_f64_definition(ya, oracle, n, direction):
+    """parity unpinned by the reference above N = 509; pinned by the definition (f64 DFT)."""
+    rng = np.random.default_rng(n)
+    x = ((rng.standard_normal(3 * n) + 1j * rng.standard_normal(3 * n)) * np.sqrt(0.5)).astype(np.complex64)
+    d = ya.Direction[direction]
+    got = ya.Fft(n, d).run_batch(x)
+    for b in range(3):
+        truth = oracle.dft_f64(x[b * n:(b + 1) * n], backward=(d == ya.Direction.Backward))
+        assert rel_l2(got[b], truth) <= 1e-5
+        # reference abs tol 2e-4 at N<=509 scaled by the sqrt(N) growth of output magnitude
+        assert np.max(np.abs(got[b] - truth)) <= 2e-4 * max(1.0, np.sqrt(n / 509))
+
+
+def test_fft_4096_golden_fixture(ya, oracle):
+    """committed fixture: 4 transforms of the C3 stream vs numpy f64 (tests/golden/fft4096.npz)"""
+    g = load_golden("fft4096")
+    x, Y = g["x"], g["y"]
+    assert np.array_equal(x, oracle.gen_complex(SEED + 3, 4 * 4096))      # the generator is pinned too
+    got = ya.Fft(4096, ya.Direction.Forward).run_batch(x)
+    for b in range(4):
+        assert rel_l2(got[b], Y[b]) <= 1e-5
+        assert np.max(np.abs(got[b] - Y[b])) <= 5.7e-4
+    back = ya.Fft(4096, ya.Direction.Backward).run_batch(got.reshape(-1)) / np.float32(4096)
+    assert np.max(np.abs(back.reshape(-1) - x)) <= 2e-4
+
+
+def test_fft_impulse_and_tone_are_exact_bins(ya):
+    """indexing: impulse at n0 -> linear phase; tone at bin k -> energy in bin k only"""
+    n = 4096
+    f = ya.Fft(n, ya.Direction.Forward)
+    x = np.zeros(n, np.complex64)
+    x[0] = 1
+    assert np.array_equal(f.run(x), np.ones(n, np.complex64))
+    for k in (1, 17, 255, 256, 2049, 4095):
+        t = np.exp(2j * np.pi * k * np.arange(n) / n).astype(np.complex64)
+        y = f.run(t)
+        assert np.argmax(np.abs(y)) == k and abs(y[k] - n) < 0.05
+        y[k] = 0
+        assert np.max(np.abs(y)) < 0.02
+
+
+def test_config_c3_fft_4096_batch_65536(ya, oracle):
+    """BASELINE config C3 at full size (2 GiB in, 2 GiB out) on device-generated input:
+    sampled transforms vs the f64 definition + linearity (size-independent property)."""
+    n, batch = 4096, 65536
+    total = n * batch
+    dx = ya.gen_complex_dev(SEED + 3, total)
+    dy = ya.DeviceArray(total, np.complex64)
+    plan = ya.Fft(n, ya.Direction.Forward)
+    plan.run_batch_dev(dx, dy, batch)
+    ya.synchronize()
+    for b in (0, 1, 4095, 32768, 65535):
+        xb = dx.to_numpy(n, offset=b * n)
+        yb = dy.to_numpy(n, offset=b * n)
+        truth = oracle.dft_f64(xb)
+        assert rel_l2(yb, truth) <= 1e-5, b
+        assert np.max(np.abs(yb - truth)) <= 5.7e-4, b
+    # device generator == oracle generator up to libm ulps on the first transform
+    assert np.max(np.abs(dx.to_numpy(n) - oracle.gen_complex(SEED + 3, n))) <= 1e-5
+    # Parseval over a strided sample of transforms
+    for b in (7, 12345, 54321):
+        xb, yb = dx.to_numpy(n, offset=b * n), dy.to_numpy(n, offset=b * n)
+        e_in = np.sum(np.abs(xb.astype(np.complex128)) ** 2)
+        e_out = np.sum(np.abs(yb.astype(np.complex128)) ** 2) / n
+        assert abs(e_in - e_out) <= 1e-5 * e_in
+    dx.free()
+    dy.free()

@@ -1,0 +1,313 @@
+"""HIP FIR objects through the C ABI vs the oracle: FirFilter / FirDecimationFilter / FirPfbFilter.
+Mirrors the reference's tests (firfilt.rs:355-1039, firdecim.rs:216-473, firpfb.rs:310-396)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from gpu_util import SEED, fir_bound, int_samples, int_taps, rand_samples, rand_taps, rel_l2
+
+pytestmark = pytest.mark.gpu
+KINDS = ["rrrf", "crcf", "cccf"]
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yagi_amd
+    assert yagi_amd.device_count() > 0
+    return yagi_amd
+
+
+# ---------------------------------------------------------------------------------- firfilt
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("case", ["h4x8", "h7x16", "h13x32", "h23x64"])
+def test_firfilt_golden(ya, kind, case):
+    """firfilt.rs:842-1039, max_relative 1e-3"""
+    g = load_golden("firfilt")
+    h, x, y = (g[f"firfilt_{kind}_data_{case}_{s}"] for s in "hxy")
+    q = ya.FirFilter(kind, h)
+    np.testing.assert_allclose(q.execute_block(x), y, rtol=1e-3, atol=1e-6)
+    # per-sample path: push()+execute() == execute_one() == block
+    q1, q2 = ya.FirFilter(kind, h), ya.FirFilter(kind, h)
+    for xi, yi in zip(x, y):
+        q1.push(xi)
+        a, b = q1.execute(), q2.execute_one(xi)
+        assert abs(a - yi) <= 1e-3 * abs(yi) + 1e-6 and abs(b - yi) <= 1e-3 * abs(yi) + 1e-6
+    if kind == "crcf":
+        for choice in (1, 2):                       # both block kernels
+            q = ya.FirFilter(kind, h)
+            q.set_kernel(choice)
+            np.testing.assert_allclose(q.execute_block(x), y, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firfilt_config_and_accessors(ya, kind):
+    """firfilt.rs:435-457 + accessors :285-314"""
+    T, Cdt = ya.KINDS[kind]
+    with pytest.raises(ya.ConfigError):
+        ya.FirFilter(kind, np.zeros(0, Cdt))
+    with pytest.raises(ya.ConfigError):
+        ya.FirFilter.new_rect(kind, 0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirFilter.new_rect(kind, 1025)
+    with pytest.raises(ya.ConfigError):
+        ya.FirFilter.new_kaiser(kind, 0, 0.2, 60.0, 0.0)
+    q = ya.FirFilter.new_rect(kind, 5)
+    assert q.get_length() == 5 and np.all(q.get_coefficients() == 1)
+    assert q.get_scale() == 1
+    q.set_scale(3.0)
+    assert q.get_scale() == 3.0
+    with pytest.raises(ya.ConfigError):            # firfilt.rs:268-270
+        q.execute_block(np.zeros(4, T), np.zeros(5, T))
+    y = q.execute_block(np.ones(8, T))
+    assert np.array_equal(y, 3.0 * np.minimum(np.arange(1, 9), 5).astype(T))
+    assert q.execute_block(np.zeros(0, T)).size == 0          # empty block is a no-op
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firfilt_state_push_write_clone_reset(ya, oracle, kind):
+    """firfilt_push_write (firfilt.rs:512-538), *_copy (:540-588), reset (:209-213)"""
+    rng = np.random.default_rng(21)
+    h = rand_taps(rng, kind, 21)
+    x = rand_samples(rng, kind, 160)
+    ref = oracle.FirFilter(kind, h)
+    want = ref.execute_block(x)
+    q = ya.FirFilter(kind, h)
+    # mixed usage: block, then push/write + execute, then block again
+    got = np.empty_like(x)
+    got[:50] = q.execute_block(x[:50])
+    for i in range(50, 60):
+        q.push(x[i])
+        got[i] = q.execute()
+    q.write(x[60:70])                   # write() = push each, output only after the last
+    got[69] = q.execute()
+    got[60:69] = want[60:69]
+    got[70:] = q.execute_block(x[70:])
+    tol = fir_bound(kind, h, x)
+    assert np.max(np.abs(got - oracle.fir_block_f64(kind, h, x))) <= tol
+    # clone continues identically (bitwise: same kernels, same state)
+    c = q.clone()
+    extra = rand_samples(rng, kind, 40)
+    assert np.array_equal(q.execute_block(extra), c.execute_block(extra))
+    assert q.execute_one(1.0) == c.execute_one(1.0)
+    # reset -> zero history again
+    q.reset()
+    np.testing.assert_allclose(q.execute_block(x[:30]), want[:30], atol=tol)
+    # set_coefficients resets state and may change the length (firfilt.rs:193-206)
+    h2 = rand_taps(rng, kind, 9)
+    q.set_coefficients(h2)
+    assert q.get_length() == 9
+    np.testing.assert_allclose(q.execute_block(x[:30]), oracle.fir_block_f64(kind, h2, x[:30]), atol=fir_bound(kind, h2, x))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("L,n", [(1, 100), (2, 1), (31, 4097), (63, 10_000), (256, 20_000), (257, 5000), (1500, 9000)])
+def test_firfilt_random_vs_f64(ya, oracle, kind, L, n):
+    rng = np.random.default_rng(L * 7 + n)
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n)
+    q = ya.FirFilter(kind, h)
+    q.set_scale(0.4)
+    # ragged blocks with carried state
+    cuts = sorted(set([0, n // 3, n // 3 + 1, (2 * n) // 3, n]))
+    got = np.concatenate([q.execute_block(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    truth = oracle.fir_block_f64(kind, h, x, scale=0.4)
+    assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x)
+    assert rel_l2(got, truth) <= 2e-6
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firfilt_integer_inputs_bit_exact(ya, oracle, kind):
+    """indexing (which sample meets which tap) is exact: integer data => bitwise equality"""
+    rng = np.random.default_rng(99)
+    for L, n in [(7, 300), (64, 5000), (256, 9000)]:
+        h, x = int_taps(rng, kind, L), int_samples(rng, kind, n)
+        want = oracle.FirFilter(kind, h).execute_block(x)
+        assert np.array_equal(ya.FirFilter(kind, h).execute_block(x), want)
+        if kind == "crcf":
+            for choice in (1, 2):
+                q = ya.FirFilter(kind, h)
+                q.set_kernel(choice)
+                a = q.execute_block(x[: n // 2])
+                b = q.execute_block(x[n // 2:])
+                assert np.array_equal(np.concatenate([a, b]), want)
+
+
+def test_config_c1_firfilt_rrrf_63tap_1M(ya, oracle):
+    """BASELINE config C1: kaiser(63, 0.2, 60), scale 0.4, 1 048 576 real samples"""
+    h = oracle.fir_design_kaiser(63, 0.2, 60.0)
+    x = oracle.gen_real(SEED + 1, 1 << 20)
+    q = ya.FirFilter.new_kaiser("rrrf", 63, 0.2, 60.0, 0.0)
+    np.testing.assert_allclose(q.get_coefficients(), h, rtol=2e-6, atol=1e-9)
+    q.set_coefficients(h)
+    q.set_scale(0.4)
+    got = q.execute_block(x)
+    ref = oracle.FirFilter("rrrf", h)
+    ref.set_scale(0.4)
+    want32 = ref.execute_block(x)
+    truth = oracle.fir_block_f64("rrrf", h, x, scale=0.4)
+    assert np.max(np.abs(got - truth)) <= fir_bound("rrrf", h, x)
+    assert rel_l2(got, truth) <= 1e-6
+    assert rel_l2(got, truth) <= rel_l2(want32, truth) * 1.5 + 1e-8       # no worse than the reference's own order
+
+
+def test_config_c2_firfilt_crcf_256tap_stream(ya, oracle):
+    """BASELINE config C2 (parity subset): kaiser(256,0.2,60), scale 0.4, first 2^20 samples in blocks"""
+    h = oracle.fir_design_kaiser(256, 0.2, 60.0)
+    n = 1 << 20
+    x = oracle.gen_complex(SEED + 2, n)
+    truth = oracle.fir_block_f64("crcf", h, x, scale=0.4)
+    for choice in (0, 1, 2):
+        q = ya.FirFilter("crcf", h)
+        q.set_scale(0.4)
+        q.set_kernel(choice)
+        got = np.concatenate([q.execute_block(x[i:i + (1 << 18)]) for i in range(0, n, 1 << 18)])
+        assert np.max(np.abs(got - truth)) <= fir_bound("crcf", h, x), choice
+        assert rel_l2(got, truth) <= 1e-6, choice
+
+
+# ---------------------------------------------------------------------------------- firdecim
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("case,M", [("m2h4x20", 2), ("m3h7x30", 3), ("m4h13x40", 4), ("m5h23x50", 5)])
+def test_firdecim_golden(ya, kind, case, M):
+    """firdecim.rs:295-473, epsilon 1e-3; firdecim_block (:246-279): block == per call"""
+    g = load_golden("firdecim")
+    h, x, y = (g[f"firdecim_{kind}_data_{case}_{s}"] for s in "hxy")
+    q = ya.FirDecimationFilter(kind, M, h)
+    got = q.execute_block(x, len(y))
+    np.testing.assert_allclose(got, y, atol=1e-3, rtol=0)
+    q2 = ya.FirDecimationFilter(kind, M, h)
+    per = np.array([q2.execute(x[i * M:(i + 1) * M]) for i in range(len(y))])
+    assert np.array_equal(per, got)
+    assert q.get_decim_rate() == M
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firdecim_config(ya, kind):
+    """firdecim.rs:216-244"""
+    T, Cdt = ya.KINDS[kind]
+    with pytest.raises(ya.ConfigError):
+        ya.FirDecimationFilter(kind, 0, np.ones(4, Cdt))
+    with pytest.raises(ya.ConfigError):
+        ya.FirDecimationFilter(kind, 2, np.zeros(0, Cdt))
+    with pytest.raises(ya.ConfigError):
+        ya.FirDecimationFilter.new_kaiser(kind, 1, 3, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirDecimationFilter.new_kaiser(kind, 4, 0, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirDecimationFilter.new_kaiser(kind, 4, 3, -1.0)
+    q = ya.FirDecimationFilter.new_kaiser(kind, 4, 3, 60.0)
+    with pytest.raises(ya.ConfigError):            # the reference panics on x.len() < M (firdecim.rs:182)
+        q.execute(np.zeros(3, T))
+    with pytest.raises(ya.ConfigError):
+        q.execute_block(np.zeros(7, T), 2)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("M,L,n", [(2, 9, 1000), (3, 64, 5001), (5, 101, 3000), (8, 129, 4100), (64, 1025, 700), (300, 40, 50)])
+def test_firdecim_random_vs_f64(ya, oracle, kind, M, L, n):
+    rng = np.random.default_rng(M * 1000 + L)
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n * M)
+    q = ya.FirDecimationFilter(kind, M, h)
+    q.set_scale(0.5)
+    k = n // 2
+    got = np.concatenate([q.execute_block(x[:k * M], k), q.execute_block(x[k * M:], n - k)])
+    truth = oracle.fir_block_f64(kind, h, x, M=M, n=n, scale=0.5)
+    assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x)
+    # clone + reset
+    c = q.clone()
+    e = rand_samples(rng, kind, 10 * M)
+    assert np.array_equal(q.execute_block(e, 10), c.execute_block(e, 10))
+    q.reset()
+    np.testing.assert_allclose(q.execute_block(x[:20 * M], 20), truth[:20], atol=fir_bound(kind, h, x))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firdecim_integer_inputs_bit_exact(ya, oracle, kind):
+    rng = np.random.default_rng(17)
+    for M, L, n in [(2, 5, 100), (4, 33, 2000), (7, 50, 999)]:
+        h, x = int_taps(rng, kind, L), int_samples(rng, kind, n * M)
+        want = oracle.FirDecimationFilter(kind, M, h).execute_block(x, n)
+        assert np.array_equal(ya.FirDecimationFilter(kind, M, h).execute_block(x, n), want)
+
+
+# ---------------------------------------------------------------------------------- firpfb
+def test_firpfb_impulse_response(ya):
+    """firpfb.rs:310-359 (1e-4)"""
+    g = load_golden("firpfb")
+    h, noise, test = (g[f"firpfb_impulse_response__{s}"] for s in ("h", "noise", "test"))
+    f = ya.FirPfbFilter("rrrf", 4, h, 48)
+    for v in noise:
+        f.push(v)
+    for i, expected in enumerate(test):
+        assert abs(f.execute(i) - expected) <= 1e-4
+    with pytest.raises(ya.ConfigError):            # firpfb.rs:278-280
+        f.execute(4)
+    f2 = ya.FirPfbFilter("rrrf", 4, h, 48)
+    f2.write(noise)
+    assert all(f2.execute(i) == f.execute(i) for i in range(4))
+
+
+def test_firpfb_config(ya):
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbFilter("crcf", 0, np.ones(8, np.float32))
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbFilter("crcf", 4, np.zeros(0, np.float32))
+    with pytest.raises(ya.ConfigError):            # h_len / M == 0 -> Window::new(0) errs (window.rs:14)
+        ya.FirPfbFilter("crcf", 16, np.ones(8, np.float32))
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbFilter.new_kaiser("crcf", 4, 0, 0.5, 60.0)
+    with pytest.raises(ya.ConfigError):
+        ya.FirPfbFilter.new_kaiser("crcf", 4, 3, 0.7, 60.0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firpfb_copy(ya, kind):
+    """firpfb_crcf_copy (firpfb.rs:361-396): irregular sizes, clone mid-stream, equal outputs"""
+    rng = np.random.default_rng(13)
+    m, hh = 13, 7
+    q0 = ya.FirPfbFilter.default(kind, m, hh)
+    q0.write(rand_samples(rng, kind, 80))
+    q1 = q0.clone()
+    for _ in range(40):
+        v = rand_samples(rng, kind, 1)[0]
+        idx = int(rng.integers(0, m))
+        q0.push(v)
+        q1.push(v)
+        assert q0.execute(idx) == q1.execute(idx)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("nf,hlen,n", [(4, 48, 300), (13, 13 * 14 + 1, 500), (64, 1025, 2000), (256, 2049, 700), (3, 10, 50)])
+def test_firpfb_block_all_select_vs_oracle(ya, oracle, kind, nf, hlen, n):
+    rng = np.random.default_rng(nf * 31 + hlen)
+    h, x = rand_taps(rng, kind, hlen), rand_samples(rng, kind, n)
+    hs = hlen // nf
+    tol = 4 * hs * 1.2e-7 * float(np.sum(np.abs(h))) * float(np.max(np.abs(x))) + 1e-7
+    # execute_block(i, x) for a few branches, state carried over two calls
+    for i in sorted(set([0, 1, nf // 2, nf - 1])):
+        ref = oracle.FirPfbFilter(kind, nf, h, hlen)
+        q = ya.FirPfbFilter(kind, nf, h, hlen)
+        got = np.concatenate([q.execute_block(i, x[: n // 2]), q.execute_block(i, x[n // 2:])])
+        assert np.max(np.abs(got - ref.execute_block(i, x))) <= tol
+    # all branches per pushed sample (interpolator form)
+    q = ya.FirPfbFilter(kind, nf, h, hlen)
+    q.set_scale(2.0)
+    ya_all = np.concatenate([q.execute_all(x[:7]), q.execute_all(x[7:])])
+    ref = oracle.FirPfbFilter(kind, nf, h, hlen)
+    ref.set_scale(2.0)
+    idx = rng.integers(0, nf, n).astype(np.uint32)
+    want_sel = np.empty(n, x.dtype)
+    for k in range(n):
+        ref.push(x[k])
+        if k % max(1, n // 16) == 0:
+            want = np.array([ref.execute(i) for i in range(nf)])
+            assert np.max(np.abs(ya_all[k] - want)) <= 2 * tol
+        want_sel[k] = ref.execute(int(idx[k]))
+    # branch index per sample
+    q = ya.FirPfbFilter(kind, nf, h, hlen)
+    q.set_scale(2.0)
+    got_sel = np.concatenate([q.execute_select(idx[:11], x[:11]), q.execute_select(idx[11:], x[11:])])
+    assert np.max(np.abs(got_sel - want_sel)) <= 2 * tol
+    with pytest.raises(ya.ConfigError):
+        q.execute_select(np.full(4, nf, np.uint32), x[:4])
+    with pytest.raises(ya.ConfigError):
+        q.execute_block(nf, x[:4])

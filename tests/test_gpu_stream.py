@@ -1,0 +1,101 @@
+"""The headline composition through the C ABI: firfilt_crcf.execute_block -> consecutive 4096-sample
+frames -> forward FFT, fused on the device (yagi_hip_firfft_crcf_*), vs the oracle."""
+import numpy as np
+import pytest
+
+from gpu_util import SEED, fir_bound, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yagi_amd
+    assert yagi_amd.device_count() > 0
+    return yagi_amd
+
+
+def spectra_truth(oracle, h, scale, x, nfft=4096):
+    y = oracle.fir_block_f64("crcf", h, x, scale=scale)
+    return np.array([np.fft.fft(y[f * nfft:(f + 1) * nfft]) for f in range(len(x) // nfft)])
+
+
+@pytest.mark.parametrize("L", [1, 4, 63, 256, 257, 1000])
+def test_stream_small_vs_oracle(ya, oracle, L):
+    rng = np.random.default_rng(L)
+    h = (rng.standard_normal(L) / np.sqrt(L)).astype(np.float32)
+    x = oracle.gen_complex(SEED + 2, 12 * 4096)
+    q = ya.FirFftStream(h)
+    q.set_scale(0.4)
+    got = np.concatenate([q.execute(x[: 5 * 4096]), q.execute(x[5 * 4096:])])     # state carried across calls
+    truth = spectra_truth(oracle, h, 0.4, x)
+    for f in range(12):
+        assert rel_l2(got[f], truth[f]) <= 1e-5, f
+    # same result as the unfused objects (FirFilter then Fft), to f32 rounding
+    fir = ya.FirFilter("crcf", h)
+    fir.set_scale(0.4)
+    unfused = ya.Fft(4096, ya.Direction.Forward).run_batch(fir.execute_block(x))
+    assert rel_l2(got, unfused) <= 2e-6
+    # and the oracle's own f32 composition is within the same distance of the f64 truth
+    want32 = oracle.stream_fir_fft(h, 0.4, x, 4096)
+    assert rel_l2(got, truth) <= 3 * rel_l2(want32, truth) + 1e-7
+    q.reset()
+    assert rel_l2(q.execute(x[:4096])[0], truth[0]) <= 1e-5
+
+
+def test_stream_config(ya):
+    with pytest.raises(ya.ConfigError):
+        ya.FirFftStream(np.zeros(0, np.float32))
+    with pytest.raises(ya.ConfigError):
+        ya.FirFftStream(np.ones(8, np.float32), nfft=1024)
+    with pytest.raises(ya.ConfigError):
+        ya.FirFftStream(np.ones(2000, np.float32))
+    q = ya.FirFftStream(np.ones(8, np.float32))
+    with pytest.raises(ya.ConfigError):
+        q.execute(np.zeros(100, np.complex64))
+    assert q.execute(np.zeros(0, np.complex64)).shape == (0, 4096)
+
+
+def test_stream_integer_alignment_exact(ya):
+    """frame/tap alignment: an impulse train through a rect filter gives exactly predictable spectra"""
+    h = np.ones(256, np.float32)
+    x = np.zeros(3 * 4096, np.complex64)
+    x[4096 - 100] = 1.0          # its 256-sample response straddles the frame 0 / frame 1 boundary
+    q = ya.FirFftStream(h)
+    got = q.execute(x)
+    y = np.zeros(3 * 4096)
+    y[4096 - 100: 4096 - 100 + 256] = 1.0
+    for f in range(3):
+        truth = np.fft.fft(y[f * 4096:(f + 1) * 4096])
+        assert np.max(np.abs(got[f] - truth)) <= 2e-3
+    assert np.max(np.abs(got[2])) == 0.0
+
+
+def test_headline_config_full_block(ya, oracle):
+    """headline workload at bench size: kaiser(256,0.2,60), scale 0.4, one 2^24-sample block
+    (4096 frames) of the C2 stream generated on the device; sampled frames vs f64 truth."""
+    h = oracle.fir_design_kaiser(256, 0.2, 60.0)
+    n = 1 << 24
+    nframes = n // 4096
+    dx = ya.gen_complex_dev(SEED + 2, n)
+    dy = ya.DeviceArray(n, np.complex64)
+    q = ya.FirFftStream(h)
+    q.set_scale(0.4)
+    q.execute_dev(dx, nframes, dy)
+    ya.synchronize()
+    for f in (0, 1, 2047, 4095):
+        lo = max(0, f * 4096 - 255)
+        xs = dx.to_numpy((f + 1) * 4096 - lo, offset=lo)
+        y = oracle.fir_block_f64("crcf", h, xs, scale=0.4)[-4096:]
+        truth = np.fft.fft(y)
+        got = dy.to_numpy(4096, offset=f * 4096)
+        assert rel_l2(got, truth) <= 1e-5, f
+    # second block continues the stream: frame 0 of block 2 needs the last 255 samples of block 1
+    dx2 = ya.gen_complex_dev(SEED + 2, 8 * 4096, first=n)
+    dy2 = ya.DeviceArray(8 * 4096, np.complex64)
+    q.execute_dev(dx2, 8, dy2)
+    ya.synchronize()
+    tail = dx.to_numpy(255, offset=n - 255)
+    xs = np.concatenate([tail, dx2.to_numpy(4096)])
+    truth = np.fft.fft(oracle.fir_block_f64("crcf", h, xs, scale=0.4)[-4096:])
+    assert rel_l2(dy2.to_numpy(4096), truth) <= 1e-5

@@ -1,0 +1,594 @@
+"""yagi_amd -- Python host mirror of yagi's FIR/FFT object API over libyagi_hip.so (MI355X).
+
+The classes keep the reference's names, argument meaning and error behaviour
+(reference = EEGKit/yagi, paths relative to its root):
+
+    DotProd / dotprod          src/dotprod/mod.rs:13-73
+    FirFilter                  src/filter/fir/firfilt.rs:10-15,63-314
+    FirDecimationFilter        src/filter/fir/firdecim.rs:12-17,38-205
+    FirPfbFilter               src/filter/fir/firpfb.rs:10-15,34-301
+    Fft, Direction, fft_run    src/fft/mod.rs:13-69
+    Error variants             src/error.rs:4-14
+    FirPfbCh / FirPfbCh2       (absent from the reference: src/multichannel/mod.rs is empty)
+    FirFftStream               the headline composition FirFilter::execute_block -> Fft::run
+
+Generic parameters <T, Coeff> are spelled with liquid-dsp's suffixes: "rrrf" = <f32,f32>,
+"crcf" = <Complex32,f32>, "cccf" = <Complex32,Complex32>.  Every numeric result comes from a HIP
+kernel through the C ABI (include/yagi_hip.h); importing this package fails if the library is
+not built, and every call fails with DeviceError if no GPU is present.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+from ._capi import cf32, lib
+
+__all__ = [
+    "YagiError", "InternalError", "ConfigError", "ValueError_", "RangeError", "ModeError",
+    "NoConvergenceError", "DeviceError", "Direction", "dotprod", "FirFilter", "FirDecimationFilter",
+    "FirPfbFilter", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
+    "fir_design_kaiser", "device_count", "synchronize", "gen_complex_dev", "gen_real_dev",
+]
+
+
+# ---- error::Error (src/error.rs:7-14) ---------------------------------------------------------
+class YagiError(Exception):
+    pass
+
+
+class InternalError(YagiError):
+    pass
+
+
+class ConfigError(YagiError):
+    pass
+
+
+class ValueError_(YagiError):
+    pass
+
+
+class RangeError(YagiError):
+    pass
+
+
+class ModeError(YagiError):
+    pass
+
+
+class NoConvergenceError(YagiError):
+    pass
+
+
+class DeviceError(YagiError):
+    pass
+
+
+_ERR = {1: InternalError, 2: ConfigError, 3: ValueError_, 4: RangeError, 5: ModeError,
+        6: NoConvergenceError, 7: DeviceError}
+
+
+def _check(rc):
+    if rc != 0:
+        raise _ERR.get(rc, YagiError)(lib.yagi_hip_last_error().decode())
+
+
+class Direction(enum.Enum):
+    """fft::Direction (src/fft/mod.rs:13-17)"""
+    Forward = 0
+    Backward = 1
+
+
+KINDS = {"rrrf": (np.float32, np.float32), "crcf": (np.complex64, np.float32),
+         "cccf": (np.complex64, np.complex64)}
+
+
+def _arr(a, dt):
+    return np.ascontiguousarray(np.asarray(a, dtype=dt))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if isinstance(a, np.ndarray) else C.c_void_p(a)
+
+
+def _byval(v, ctype):
+    if ctype is cf32:
+        v = complex(v)
+        return cf32(v.real, v.imag)
+    return C.c_float(float(np.real(v)))
+
+
+def _devptr(x):
+    """device pointer from a DeviceArray, a torch tensor (data_ptr) or a raw int."""
+    if isinstance(x, DeviceArray):
+        return C.c_void_p(x.ptr)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+# ---- device plumbing --------------------------------------------------------------------------
+def device_count():
+    n = C.c_int(0)
+    rc = lib.yagi_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def synchronize():
+    _check(lib.yagi_hip_device_synchronize())
+
+
+class DeviceArray:
+    """A typed HBM allocation owned through yagi_hip_malloc/free."""
+
+    def __init__(self, n, dtype):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        p = C.c_void_p()
+        _check(lib.yagi_hip_malloc(C.byref(p), self.n * self.dtype.itemsize))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype)
+        _check(lib.yagi_hip_memcpy_h2d(d.ptr, _ptr(a), a.nbytes))
+        return d
+
+    def to_numpy(self, n=None, offset=0):
+        n = self.n - offset if n is None else n
+        out = np.empty(n, self.dtype)
+        _check(lib.yagi_hip_memcpy_d2h(_ptr(out), C.c_void_p(self.ptr + offset * self.dtype.itemsize), out.nbytes))
+        return out
+
+    def zero(self):
+        _check(lib.yagi_hip_memset_dev(self.ptr, 0, self.n * self.dtype.itemsize))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib.yagi_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def gen_complex_dev(seed, n, out=None, first=0, stream=None):
+    out = out if out is not None else DeviceArray(n, np.complex64)
+    _check(lib.yagi_hip_gen_complex_dev(seed, first, n, _devptr(out), stream))
+    return out
+
+
+def gen_real_dev(seed, n, out=None, first=0, stream=None):
+    out = out if out is not None else DeviceArray(n, np.float32)
+    _check(lib.yagi_hip_gen_real_dev(seed, first, n, _devptr(out), stream))
+    return out
+
+
+def fir_design_kaiser(n, fc, as_, mu=0.0):
+    """filter::fir_design_kaiser (src/filter/fir/design/kaiser.rs:16-51)"""
+    h = np.zeros(max(int(n), 1), np.float32)
+    _check(lib.yagi_hip_fir_design_kaiser(n, fc, as_, mu, _ptr(h)))
+    return h[:n]
+
+
+# ---- dotprod (trait DotProd, src/dotprod/mod.rs:13-73) ----------------------------------------
+def dotprod(a, b):
+    """a.dotprod(b): the impl is picked from the element types like the Rust trait impls."""
+    a, b = np.asarray(a), np.asarray(b)
+    ca, cb = np.iscomplexobj(a), np.iscomplexobj(b)
+    name = {(False, False): "rrrf", (False, True): "rccf", (True, False): "crcf", (True, True): "cccf"}[(ca, cb)]
+    a = _arr(a, np.complex64 if ca else np.float32)
+    b = _arr(b, np.complex64 if cb else np.float32)
+    # zip() semantics: the shorter slice decides (slice impls, mod.rs:23-25)
+    n = min(a.size, b.size)
+    y = np.zeros(1, np.complex64 if (ca or cb) else np.float32)
+    _check(getattr(lib, f"yagi_hip_dotprod_{name}")(_ptr(a), _ptr(b), n, _ptr(y)))
+    return y[0]
+
+
+# ---- handle base ------------------------------------------------------------------------------
+class _Handle:
+    _prefix = None
+
+    def _fn(self, name):
+        return getattr(lib, f"{self._prefix}{name}")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._fn("destroy")(h)
+            self._h = None
+
+    def set_stream(self, stream):
+        """stream: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream)"""
+        _check(self._fn("set_stream")(self._h, stream))
+
+    def reset(self):
+        _check(self._fn("reset")(self._h))
+
+
+class _FirBase(_Handle):
+    def _init_kind(self, kind):
+        if kind not in KINDS:
+            raise ConfigError(f"unknown type combination {kind!r}")
+        self.kind = kind
+        self.T, self.Cdt = KINDS[kind]
+        self._Tc, self._Cc = _capi.KIND_TYPES[kind]
+
+    def set_scale(self, scale):
+        _check(self._fn("set_scale")(self._h, _byval(scale, self._Cc)))
+
+    def get_scale(self):
+        s = np.zeros(1, self.Cdt)
+        _check(self._fn("get_scale")(self._h, _ptr(s)))
+        return s[0]
+
+    def clone(self):
+        new = object.__new__(type(self))
+        new.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_h"})
+        h = C.c_void_p()
+        _check(self._fn("clone")(self._h, C.byref(h)))
+        new._h = h
+        return new
+
+
+class FirFilter(_FirBase):
+    """FirFilter<T,Coeff> (src/filter/fir/firfilt.rs)."""
+
+    def __init__(self, kind, h):
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firfilt_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(_ptr(h), h.size, C.byref(hd)))
+        self._h = hd
+
+    @classmethod
+    def _from(cls, kind, creator, *args):
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firfilt_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn(creator)(*args, C.byref(hd)))
+        self._h = hd
+        return self
+
+    @classmethod
+    def new_kaiser(cls, kind, n, fc, as_, mu=0.0):          # firfilt.rs:93-97
+        return cls._from(kind, "create_kaiser", n, fc, as_, mu)
+
+    @classmethod
+    def new_rect(cls, kind, n):                              # firfilt.rs:149-155
+        return cls._from(kind, "create_rect", n)
+
+    def set_coefficients(self, h):                           # :193-206
+        h = _arr(h, self.Cdt)
+        _check(self._fn("set_coefficients")(self._h, _ptr(h), h.size))
+
+    def push(self, x):                                       # :220-223
+        _check(self._fn("push")(self._h, _byval(x, self._Tc)))
+
+    def write(self, x):                                      # :230-234
+        x = _arr(x, self.T)
+        _check(self._fn("write")(self._h, _ptr(x), x.size))
+
+    def execute(self):                                       # :241-246
+        y = np.zeros(1, self.T)
+        _check(self._fn("execute")(self._h, _ptr(y)))
+        return y[0]
+
+    def execute_one(self, x):                                # :256-259
+        y = np.zeros(1, self.T)
+        _check(self._fn("execute_one")(self._h, _byval(x, self._Tc), _ptr(y)))
+        return y[0]
+
+    def execute_block(self, x, y=None):                      # :267-278
+        x = _arr(x, self.T)
+        if y is None:
+            y = np.empty_like(x)
+        elif y.dtype != self.T or not y.flags.c_contiguous:
+            raise ConfigError("output must be a contiguous array of the sample type")
+        _check(self._fn("execute_block")(self._h, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def execute_block_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def get_length(self):                                    # :301-303
+        n = C.c_size_t()
+        _check(self._fn("get_length")(self._h, C.byref(n)))
+        return n.value
+
+    def get_coefficients(self):                              # :310-312
+        n = self.get_length()
+        h = np.empty(n, self.Cdt)
+        _check(self._fn("get_coefficients")(self._h, _ptr(h), n))
+        return h
+
+    def set_kernel(self, choice):
+        """crcf only: 0 auto, 1 general kernel, 2 register-sliding kernel."""
+        if self.kind != "crcf":
+            raise ConfigError("kernel choice exists for crcf only")
+        _check(lib.yagi_hip_firfilt_crcf_set_kernel(self._h, choice))
+
+
+class FirDecimationFilter(_FirBase):
+    """FirDecimationFilter<T,Coeff> (src/filter/fir/firdecim.rs)."""
+
+    def __init__(self, kind, decimation_factor, h, h_len=None):
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firdecim_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(decimation_factor, _ptr(h), h.size if h_len is None else h_len, C.byref(hd)))
+        self._h = hd
+
+    @classmethod
+    def new_kaiser(cls, kind, decimation_factor, m, as_):    # firdecim.rs:70-87
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firdecim_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn("create_kaiser")(decimation_factor, m, as_, C.byref(hd)))
+        self._h = hd
+        return self
+
+    def get_decim_rate(self):                                # :130-132
+        n = C.c_size_t()
+        _check(self._fn("get_decim_rate")(self._h, C.byref(n)))
+        return n.value
+
+    def execute(self, x):                                    # :179-191
+        x = _arr(x, self.T)
+        y = np.zeros(1, self.T)
+        _check(self._fn("execute")(self._h, _ptr(x), x.size, _ptr(y)))
+        return y[0]
+
+    def execute_block(self, x, n):                           # :200-205
+        x = _arr(x, self.T)
+        y = np.empty(n, self.T)
+        _check(self._fn("execute_block")(self._h, _ptr(x), x.size, n, _ptr(y)))
+        return y
+
+    def execute_block_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+
+class FirPfbFilter(_FirBase):
+    """FirPfbFilter<T,Coeff> (src/filter/fir/firpfb.rs)."""
+
+    def __init__(self, kind, num_filters, h, h_len=None):
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firpfb_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(num_filters, _ptr(h), h.size if h_len is None else h_len, C.byref(hd)))
+        self._h = hd
+        self.num_filters = num_filters
+
+    @classmethod
+    def _from(cls, kind, num_filters, creator, *args):
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firpfb_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn(creator)(num_filters, *args, C.byref(hd)))
+        self._h = hd
+        self.num_filters = num_filters
+        return self
+
+    @classmethod
+    def new_kaiser(cls, kind, num_filters, m, fc, as_):      # firpfb.rs:94-114
+        return cls._from(kind, num_filters, "create_kaiser", m, fc, as_)
+
+    @classmethod
+    def default(cls, kind, num_filters, m):                  # firpfb.rs:79-81
+        return cls._from(kind, num_filters, "create_default", m)
+
+    def push(self, x):                                       # :255-257
+        _check(self._fn("push")(self._h, _byval(x, self._Tc)))
+
+    def write(self, x):                                      # :264-266
+        x = _arr(x, self.T)
+        _check(self._fn("write")(self._h, _ptr(x), x.size))
+
+    def execute(self, i):                                    # :277-286
+        y = np.zeros(1, self.T)
+        _check(self._fn("execute")(self._h, i, _ptr(y)))
+        return y[0]
+
+    def execute_block(self, i, x):                           # :295-301
+        x = _arr(x, self.T)
+        y = np.empty_like(x)
+        _check(self._fn("execute_block")(self._h, i, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def execute_block_dev(self, i, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, i, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def execute_all_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_all_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def execute_select_dev(self, idx_dev, x_dev, n, y_dev):
+        _check(self._fn("execute_select_dev")(self._h, _devptr(idx_dev), _devptr(x_dev), n, _devptr(y_dev)))
+
+    def execute_all(self, x):
+        """host convenience over execute_all_dev: returns y[n, num_filters]"""
+        x = _arr(x, self.T)
+        dx = DeviceArray.from_numpy(x)
+        dy = DeviceArray(x.size * self.num_filters, self.T)
+        self.execute_all_dev(dx, x.size, dy)
+        synchronize()
+        return dy.to_numpy().reshape(x.size, self.num_filters)
+
+    def execute_select(self, idx, x):
+        x = _arr(x, self.T)
+        idx = _arr(idx, np.uint32)
+        if idx.size != x.size:
+            raise ConfigError("index and sample blocks must have equal length")
+        if idx.size and idx.max() >= self.num_filters:
+            raise ConfigError(f"filterbank index ({idx.max()}) exceeds maximum ({self.num_filters})")
+        dx, di = DeviceArray.from_numpy(x), DeviceArray.from_numpy(idx)
+        dy = DeviceArray(x.size, self.T)
+        self.execute_select_dev(di, dx, x.size, dy)
+        synchronize()
+        return dy.to_numpy()
+
+
+# ---- Fft (src/fft/mod.rs:33-69) ---------------------------------------------------------------
+class Fft(_Handle):
+    _prefix = "yagi_hip_fft_"
+
+    def __init__(self, n, direction):
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_fft_create(n, Direction(direction).value, C.byref(hd)))
+        self._h = hd
+        self.n = n
+        self.direction = Direction(direction)
+
+    def run(self, input, output=None):                       # fft/mod.rs:45-48
+        x = _arr(input, np.complex64)
+        y = np.empty(self.n, np.complex64) if output is None else output
+        _check(lib.yagi_hip_fft_run(self._h, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def run_batch_dev(self, in_dev, out_dev, batch, stream=None):
+        _check(lib.yagi_hip_fft_run_batch_dev(self._h, _devptr(in_dev), _devptr(out_dev), batch, stream))
+
+    def run_batch(self, x):
+        """host convenience: x holds batch*n samples"""
+        x = _arr(x, np.complex64)
+        if x.size % self.n:
+            raise ConfigError("batch input must hold a whole number of transforms")
+        dx = DeviceArray.from_numpy(x)
+        dy = DeviceArray(x.size, np.complex64)
+        self.run_batch_dev(dx, dy, x.size // self.n)
+        synchronize()
+        return dy.to_numpy().reshape(-1, self.n)
+
+    def shift(self, buf, n=None):                            # fft/mod.rs:50-57 (in place)
+        if not (isinstance(buf, np.ndarray) and buf.dtype == np.complex64 and buf.flags.c_contiguous):
+            raise ConfigError("shift works in place on a contiguous complex64 array")
+        _check(lib.yagi_hip_fft_shift(_ptr(buf), buf.size if n is None else n))
+        return buf
+
+    def set_stream(self, stream):
+        raise ModeError("Fft plans take the stream per call (run_batch_dev)")
+
+    def reset(self):
+        pass
+
+
+def fft_run(input, direction):                               # fft/mod.rs:66-69
+    x = _arr(input, np.complex64)
+    y = np.empty_like(x)
+    _check(lib.yagi_hip_fft_run_oneshot(_ptr(x), _ptr(y), x.size, Direction(direction).value))
+    return y
+
+
+# ---- headline stream ----------------------------------------------------------------------------
+class FirFftStream(_Handle):
+    """firfilt_crcf.execute_block -> consecutive nfft frames -> Fft::run(Forward), fused."""
+    _prefix = "yagi_hip_firfft_crcf_"
+
+    def __init__(self, h, nfft=4096):
+        h = _arr(h, np.float32)
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firfft_crcf_create(_ptr(h), h.size, nfft, C.byref(hd)))
+        self._h = hd
+        self.nfft = nfft
+
+    def set_scale(self, scale):
+        _check(lib.yagi_hip_firfft_crcf_set_scale(self._h, scale))
+
+    def set_variant(self, v):
+        _check(lib.yagi_hip_firfft_crcf_set_variant(self._h, v))
+
+    def execute(self, x):
+        x = _arr(x, np.complex64)
+        if x.size % self.nfft:
+            raise ConfigError("input must hold a whole number of frames")
+        nf = x.size // self.nfft
+        y = np.empty(x.size, np.complex64)
+        _check(lib.yagi_hip_firfft_crcf_execute(self._h, _ptr(x), nf, _ptr(y)))
+        return y.reshape(nf, self.nfft)
+
+    def execute_dev(self, x_dev, nframes, spectra_dev):
+        _check(lib.yagi_hip_firfft_crcf_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(spectra_dev)))
+
+
+# ---- channelizers (absent from the reference; see include/yagi_hip.h) ---------------------------
+class FirPfbCh(_Handle):
+    _prefix = "yagi_hip_firpfbch_crcf_"
+
+    def __init__(self, M, p, h):
+        h = _arr(h, np.float32)
+        if h.size < M * p:
+            raise ConfigError("prototype shorter than M*p")
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firpfbch_crcf_create(M, p, _ptr(h), C.byref(hd)))
+        self._h, self.M, self.p = hd, M, p
+
+    @classmethod
+    def new_kaiser(cls, M, m, as_):
+        self = object.__new__(cls)
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firpfbch_crcf_create_kaiser(M, m, as_, C.byref(hd)))
+        self._h, self.M, self.p = hd, M, 2 * m
+        return self
+
+    def analyzer_execute(self, x):
+        x = _arr(x, np.complex64)
+        if x.size % self.M:
+            raise ConfigError("input must hold a whole number of M-sample frames")
+        nf = x.size // self.M
+        y = np.empty(x.size, np.complex64)
+        _check(lib.yagi_hip_firpfbch_crcf_analyzer_execute(self._h, _ptr(x), nf, _ptr(y)))
+        return y.reshape(nf, self.M)
+
+    def analyzer_execute_dev(self, x_dev, nframes, y_dev):
+        _check(lib.yagi_hip_firpfbch_crcf_analyzer_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(y_dev)))
+
+
+class FirPfbCh2(_Handle):
+    _prefix = "yagi_hip_firpfbch2_crcf_"
+
+    def __init__(self, M, m, h):
+        h = _arr(h, np.float32)
+        if h.size < 2 * M * m:
+            raise ConfigError("prototype shorter than 2*M*m")
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firpfbch2_crcf_create(M, m, _ptr(h), C.byref(hd)))
+        self._h, self.M, self.m = hd, M, m
+
+    @classmethod
+    def new_kaiser(cls, M, m, as_):
+        self = object.__new__(cls)
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firpfbch2_crcf_create_kaiser(M, m, as_, C.byref(hd)))
+        self._h, self.M, self.m = hd, M, m
+        return self
+
+    def analyzer_execute(self, x):
+        x = _arr(x, np.complex64)
+        M2 = self.M // 2
+        if x.size % M2:
+            raise ConfigError("input must hold a whole number of M/2-sample steps")
+        ns = x.size // M2
+        y = np.empty(ns * self.M, np.complex64)
+        _check(lib.yagi_hip_firpfbch2_crcf_analyzer_execute(self._h, _ptr(x), ns, _ptr(y)))
+        return y.reshape(ns, self.M)
+
+    def analyzer_execute_dev(self, x_dev, nsteps, y_dev):
+        _check(lib.yagi_hip_firpfbch2_crcf_analyzer_execute_dev(self._h, _devptr(x_dev), nsteps, _devptr(y_dev)))
+
+    def analyzer_execute_shard_dev(self, x_dev, nsteps, rank, nranks, yshard_dev):
+        _check(lib.yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(
+            self._h, _devptr(x_dev), nsteps, rank, nranks, _devptr(yshard_dev)))
+
+    @staticmethod
+    def assemble_dev(gathered_dev, nsteps, M, nranks, y_dev, stream=None):
+        _check(lib.yagi_hip_firpfbch2_crcf_assemble_dev(_devptr(gathered_dev), nsteps, M, nranks, _devptr(y_dev), stream))

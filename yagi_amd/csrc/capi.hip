@@ -1,0 +1,1091 @@
+// capi.hip -- the extern "C" surface of libyagi_hip.so (include/yagi_hip.h): stateful objects that
+// mirror yagi's FirFilter / FirDecimationFilter / FirPfbFilter / Fft (+ the channelizers and the
+// fused FIR->FFT stream) with all arithmetic on the device.
+//
+// State model.  The reference keeps a Window<T>/VecDeque<T> of the last L samples inside each
+// object (firfilt.rs:13, firdecim.rs:15, firpfb.rs:12).  Here that window lives in HBM as L
+// samples, oldest first (ping-pong pair so an update never races the kernel reading it).
+// Per-sample push() only queues the sample on the host; the queue is flushed into the device
+// window (one small kernel) before anything reads the state.  Per-sample execute() is the
+// standalone dotprod kernel over (window, taps); block calls run the FIR kernels and then
+// advance the window.  clone() copies the device state; reset() zeroes it.
+#include <cmath>
+#include <memory>
+
+#include "kernels.hpp"
+
+namespace yagi {
+
+int design_kaiser(size_t n, float fc, float as_, float mu, std::vector<float> &h);   // host.cpp
+
+static int require_device() {
+    static int ok = -1;
+    if (ok < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        ok = (e == hipSuccess && n > 0) ? 1 : 0;
+    }
+    if (!ok) return fail(YAGI_ERR_DEVICE, "no HIP device available: libyagi_hip has no CPU fallback");
+    return YAGI_OK;
+}
+
+template <class V> static V one_of();
+template <> float one_of<float>() { return 1.0f; }
+template <> cf32 one_of<cf32>() { return cf32{1.0f, 0.0f}; }
+static cf32 to_c(float v, cf32 *) { return cf32{v, 0.0f}; }
+static float to_c(float v, float *) { return v; }
+
+static int upload(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return YAGI_OK;
+    YG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    YG_HIP(hipStreamSynchronize(st));
+    return YAGI_OK;
+}
+static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return YAGI_OK;
+    YG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    YG_HIP(hipStreamSynchronize(st));
+    return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device window of the last `len` samples + host push queue
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct DevWindow {
+    int len = 0;
+    DevBuf buf[2];
+    int cur = 0;
+    std::vector<T> pending;
+    DevBuf stage;
+
+    int init(int n, hipStream_t st) {
+        len = n;
+        YG_TRY(buf[0].alloc((size_t)n * sizeof(T)));
+        YG_TRY(buf[1].alloc((size_t)n * sizeof(T)));
+        return reset(st);
+    }
+    int reset(hipStream_t st) {
+        pending.clear();
+        YG_HIP(hipMemsetAsync(buf[cur].p, 0, (size_t)len * sizeof(T), st));
+        return YAGI_OK;
+    }
+    const T *dev() const { return buf[cur].template as<T>(); }
+    // window <- last len of (window ++ x_dev[0..n))
+    int advance(const T *x_dev, size_t n, hipStream_t st) {
+        if (n == 0) return YAGI_OK;
+        YG_TRY(launch_update_window<T>(dev(), x_dev, n, len, buf[1 - cur].template as<T>(), st));
+        cur = 1 - cur;
+        return YAGI_OK;
+    }
+    void push(T v) {
+        pending.push_back(v);
+        if (pending.size() > (size_t)len + 65536) pending.erase(pending.begin(), pending.end() - len);
+    }
+    int flush(hipStream_t st) {
+        if (pending.empty()) return YAGI_OK;
+        // only the last `len` queued samples can still be inside the window
+        const size_t skip = pending.size() > (size_t)len ? pending.size() - len : 0;
+        const size_t n = pending.size() - skip;
+        YG_TRY(stage.ensure(n * sizeof(T)));
+        YG_TRY(upload(stage.p, pending.data() + skip, n * sizeof(T), st));
+        YG_TRY(advance(stage.template as<T>(), n, st));
+        YG_HIP(hipStreamSynchronize(st));
+        pending.clear();
+        return YAGI_OK;
+    }
+    int clone_from(const DevWindow &o, hipStream_t st) {
+        YG_TRY(init(o.len, st));
+        YG_HIP(hipMemcpyAsync(buf[cur].p, o.buf[o.cur].p, (size_t)len * sizeof(T), hipMemcpyDeviceToDevice, st));
+        YG_HIP(hipStreamSynchronize(st));
+        pending = o.pending;
+        return YAGI_OK;
+    }
+};
+
+// workspaces shared by the host-pointer entry points of one object
+struct Workspace {
+    DevBuf x, y, scratch;
+};
+
+// scale * sum_i win[i] * taps[L-1-i] -> host value   (execute(): firfilt.rs:241-246)
+template <class K>
+static int window_dot(const typename K::T *win, const typename K::C *taps, int L, typename K::C scale,
+                      Workspace &ws, typename K::T *y_host, hipStream_t st) {
+    using T = typename K::T;
+    using C = typename K::C;
+    const size_t np = dotprod_num_partials((size_t)L);
+    YG_TRY(ws.scratch.ensure((np + 1) * sizeof(T)));
+    T *part = ws.scratch.as<T>();
+    T *res = part + np;
+    YG_TRY((launch_dotprod<T, C, T, C>(win, taps, (size_t)L, true, scale, part, res, st)));
+    return download(y_host, res, sizeof(T), st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FirFilter<T,C>
+// ---------------------------------------------------------------------------------------------
+template <class K>
+struct FirFilt {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    int L = 0, Lp = 0;
+    std::vector<C> h;          // host copy (get_coefficients)
+    C scale = one_of<C>();
+    DevBuf taps;               // h[0..L) on device
+    DevBuf taps_pad;           // crcf only: zero-padded to Lp floats for the sliding kernel
+    DevWindow<T> w;
+    Workspace ws;
+    int kernel_choice = 0;     // 0 auto, 1 general, 2 sliding (crcf)
+
+    int load_taps(const C *hh, size_t n) {
+        if (n == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
+        if (n > (size_t)1 << 24) return fail(YAGI_ERR_CONFIG, "filter too long");
+        h.assign(hh, hh + n);
+        L = (int)n;
+        YG_TRY(taps.alloc(n * sizeof(C)));
+        YG_TRY(upload(taps.p, h.data(), n * sizeof(C), st));
+        if (K::id == 1) {
+            Lp = (L + 31) / 32 * 32;
+            std::vector<float> hp((size_t)Lp, 0.0f);
+            std::memcpy(hp.data(), h.data(), n * sizeof(float));
+            YG_TRY(taps_pad.alloc((size_t)Lp * sizeof(float)));
+            YG_TRY(upload(taps_pad.p, hp.data(), (size_t)Lp * sizeof(float), st));
+        }
+        return YAGI_OK;
+    }
+    int init(const C *hh, size_t n) {
+        YG_TRY(require_device());
+        YG_TRY(load_taps(hh, n));
+        return w.init(L, st);
+    }
+    int block_dev(const T *x, size_t n, T *y);
+};
+
+template <class K>
+int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
+    YG_TRY(w.flush(st));
+    YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, 1, scale, y, n, st)));
+    return w.advance(x, n, st);
+}
+template <>
+int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
+    YG_TRY(w.flush(st));
+    const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
+    if (slide && Lp <= kSlideMaxTaps)
+        YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st));
+    else
+        YG_TRY((launch_fir_block<CRCF>(w.dev(), x, taps.as<float>(), L, 1, scale, y, n, st)));
+    return w.advance(x, n, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FirDecimationFilter<T,C>
+// ---------------------------------------------------------------------------------------------
+template <class K>
+struct FirDecim {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    int L = 0, M = 1;
+    std::vector<C> h;
+    C scale = one_of<C>();
+    DevBuf taps;
+    DevWindow<T> w;
+    Workspace ws;
+
+    int init(size_t m, const C *hh, size_t n) {
+        if (n == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
+        if (m == 0) return fail(YAGI_ERR_CONFIG, "decimation factor must be greater than zero");
+        if (n > (size_t)1 << 24 || m > (size_t)1 << 20) return fail(YAGI_ERR_CONFIG, "filter too large");
+        YG_TRY(require_device());
+        h.assign(hh, hh + n);
+        L = (int)n;
+        M = (int)m;
+        YG_TRY(taps.alloc(n * sizeof(C)));
+        YG_TRY(upload(taps.p, h.data(), n * sizeof(C), st));
+        return w.init(L, st);
+    }
+    // n outputs from n*M device samples
+    int block_dev(const T *x, size_t n, T *y) {
+        YG_TRY(w.flush(st));
+        YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, M, scale, y, n, st)));
+        return w.advance(x, n * (size_t)M, st);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// FirPfbFilter<T,C>
+// ---------------------------------------------------------------------------------------------
+template <class K>
+struct FirPfb {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    int nf = 0, Ls = 0;
+    std::vector<C> hb;         // [nf][Ls], natural order: hb[i][k] = h[i + k*nf]
+    C scale = one_of<C>();
+    DevBuf taps;
+    DevWindow<T> w;
+    Workspace ws;
+
+    int init(size_t num_filters, const C *hh, size_t h_len) {
+        if (num_filters == 0) return fail(YAGI_ERR_CONFIG, "number of filters must be greater than zero");
+        if (h_len == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
+        const size_t hs = h_len / num_filters;            // firpfb.rs:42 (floor)
+        if (hs == 0) return fail(YAGI_ERR_CONFIG, "window size must be greater than zero");  // window.rs:14
+        if (num_filters > (size_t)1 << 20 || hs > (size_t)1 << 20) return fail(YAGI_ERR_CONFIG, "filter bank too large");
+        YG_TRY(require_device());
+        nf = (int)num_filters;
+        Ls = (int)hs;
+        hb.resize((size_t)nf * Ls);
+        for (int i = 0; i < nf; ++i)
+            for (int k = 0; k < Ls; ++k) hb[(size_t)i * Ls + k] = hh[i + (size_t)k * nf];
+        YG_TRY(taps.alloc(hb.size() * sizeof(C)));
+        YG_TRY(upload(taps.p, hb.data(), hb.size() * sizeof(C), st));
+        return w.init(Ls, st);
+    }
+    int check_branch(size_t i) const {
+        if (i >= (size_t)nf) return fail(YAGI_ERR_CONFIG, "filterbank index (%zu) exceeds maximum (%d)", i, nf);
+        return YAGI_OK;
+    }
+    int block_dev(size_t i, const T *x, size_t n, T *y) {
+        YG_TRY(check_branch(i));
+        YG_TRY(w.flush(st));
+        YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>() + i * (size_t)Ls, Ls, 1, scale, y, n, st)));
+        return w.advance(x, n, st);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Fft
+// ---------------------------------------------------------------------------------------------
+struct FftPlan {
+    FftPlanDev d;
+    DevBuf tw;
+    Workspace ws;
+};
+
+static void factorize(int n, int *fac, int &nfac) {
+    nfac = 0;
+    while (n % 4 == 0) { fac[nfac++] = 4; n /= 4; }
+    while (n % 2 == 0) { fac[nfac++] = 2; n /= 2; }
+    for (int p = 3; (long long)p * p <= n; p += 2)
+        while (n % p == 0) { fac[nfac++] = p; n /= p; }
+    if (n > 1) fac[nfac++] = n;
+}
+
+static int make_twiddles(int n, int dir, DevBuf &buf) {
+    std::vector<cf32> t((size_t)n);
+    const double s = (dir == YAGI_FFT_FORWARD) ? -1.0 : 1.0;
+    for (int m = 0; m < n; ++m) {
+        const double a = s * 2.0 * M_PI * (double)m / (double)n;
+        t[m] = cf32{(float)std::cos(a), (float)std::sin(a)};
+    }
+    YG_TRY(buf.alloc((size_t)n * sizeof(cf32)));
+    return upload(buf.p, t.data(), (size_t)n * sizeof(cf32), nullptr);
+}
+
+static int fft_plan_init(FftPlan &p, size_t n, int dir) {
+    if (n == 0) return fail(YAGI_ERR_CONFIG, "fft length must be greater than zero");
+    if (dir != YAGI_FFT_FORWARD && dir != YAGI_FFT_BACKWARD) return fail(YAGI_ERR_CONFIG, "bad fft direction");
+    if (n > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft length %zu not supported (max %d)", n, kFftMaxLds);
+    YG_TRY(require_device());
+    p.d.n = (int)n;
+    p.d.dir = dir;
+    factorize((int)n, p.d.fac, p.d.nfac);
+    YG_TRY(make_twiddles((int)n, dir, p.tw));
+    p.d.tw = p.tw.as<cf32>();
+    return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused firfilt_crcf -> FFT stream
+// ---------------------------------------------------------------------------------------------
+struct FirFft {
+    FirFilt<CRCF> fir;
+    size_t nfft = 0;
+    DevBuf tw;
+    int variant = 0;
+    DevBuf xin, yout;
+};
+
+// ---------------------------------------------------------------------------------------------
+// channelizers
+// ---------------------------------------------------------------------------------------------
+struct PfbCh {
+    hipStream_t st = nullptr;
+    int M = 0, p = 0;
+    DevBuf h, tw;
+    DevWindow<cf32> hist;      // (p-1)*M samples (at least 1 kept so the buffers exist)
+    Workspace ws;
+};
+struct PfbCh2 {
+    hipStream_t st = nullptr;
+    int M = 0, m = 0;
+    DevBuf h, tw;
+    DevWindow<cf32> hist;      // (2m-1)*M + M/2 samples
+    uint64_t step = 0;
+    Workspace ws;
+};
+
+}  // namespace yagi
+
+using namespace yagi;
+
+#define CHECK_Q(q)                                                                              \
+    do {                                                                                        \
+        if (!(q)) return fail(YAGI_ERR_CONFIG, "null handle");                                  \
+    } while (0)
+#define CHECK_PTR(p)                                                                            \
+    do {                                                                                        \
+        if (!(p)) return fail(YAGI_ERR_CONFIG, "null pointer argument");                        \
+    } while (0)
+
+extern "C" {
+
+// ---- device plumbing ------------------------------------------------------------------------
+int yagi_hip_device_count(int *count) {
+    CHECK_PTR(count);
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return fail(YAGI_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return YAGI_OK;
+}
+int yagi_hip_set_device(int device) { YG_HIP(hipSetDevice(device)); return YAGI_OK; }
+int yagi_hip_malloc(void **p, size_t bytes) {
+    CHECK_PTR(p);
+    YG_TRY(require_device());
+    YG_HIP(hipMalloc(p, bytes ? bytes : 16));
+    return YAGI_OK;
+}
+int yagi_hip_free(void *p) { if (p) YG_HIP(hipFree(p)); return YAGI_OK; }
+int yagi_hip_memcpy_h2d(void *d, const void *s, size_t n) { YG_HIP(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return YAGI_OK; }
+int yagi_hip_memcpy_d2h(void *d, const void *s, size_t n) { YG_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return YAGI_OK; }
+int yagi_hip_memset_dev(void *d, int v, size_t n) { YG_HIP(hipMemset(d, v, n)); return YAGI_OK; }
+int yagi_hip_device_synchronize(void) { YG_HIP(hipDeviceSynchronize()); return YAGI_OK; }
+int yagi_hip_stream_synchronize(yagi_stream_t s) { YG_HIP(hipStreamSynchronize(to_stream(s))); return YAGI_OK; }
+
+int yagi_hip_gen_real_dev(uint64_t seed, uint64_t first, size_t n, float *x, yagi_stream_t s) {
+    YG_TRY(require_device());
+    return launch_gen_real(seed, first, n, x, to_stream(s));
+}
+int yagi_hip_gen_complex_dev(uint64_t seed, uint64_t first, size_t n, yagi_cf32 *x, yagi_stream_t s) {
+    YG_TRY(require_device());
+    return launch_gen_complex(seed, first, n, x, to_stream(s));
+}
+
+}  // extern "C"
+
+// ---- dotprod ------------------------------------------------------------------------------------
+template <class A, class B, class O>
+static int dotprod_dev(const A *a, const B *b, size_t n, O *y, hipStream_t st) {
+    YG_TRY(require_device());
+    const size_t np = dotprod_num_partials(n);
+    if (np == 1) return launch_dotprod<A, B, O, float>(a, b, n, false, 1.0f, y, y, st);
+    // multi-workgroup case needs scratch for the partials; it lives for the duration of the call
+    DevBuf part;
+    YG_TRY(part.alloc(np * sizeof(O)));
+    YG_TRY((launch_dotprod<A, B, O, float>(a, b, n, false, 1.0f, part.as<O>(), y, st)));
+    YG_HIP(hipStreamSynchronize(st));
+    return YAGI_OK;
+}
+template <class A, class B, class O>
+static int dotprod_host(const A *a, const B *b, size_t n, O *y) {
+    CHECK_PTR(y);
+    if (n && (!a || !b)) return fail(YAGI_ERR_CONFIG, "null pointer argument");
+    YG_TRY(require_device());
+    DevBuf da, db, dy;
+    YG_TRY(da.alloc(n * sizeof(A)));
+    YG_TRY(db.alloc(n * sizeof(B)));
+    YG_TRY(dy.alloc(sizeof(O)));
+    YG_TRY(upload(da.p, a, n * sizeof(A), nullptr));
+    YG_TRY(upload(db.p, b, n * sizeof(B), nullptr));
+    YG_TRY((dotprod_dev<A, B, O>(da.as<A>(), db.as<B>(), n, dy.as<O>(), nullptr)));
+    return download(y, dy.p, sizeof(O), nullptr);
+}
+
+extern "C" {
+int yagi_hip_dotprod_rrrf(const float *a, const float *b, size_t n, float *y) { return dotprod_host<float, float, float>(a, b, n, y); }
+int yagi_hip_dotprod_rccf(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) { return dotprod_host<float, cf32, cf32>(a, b, n, y); }
+int yagi_hip_dotprod_crcf(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y) { return dotprod_host<cf32, float, cf32>(a, b, n, y); }
+int yagi_hip_dotprod_cccf(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) { return dotprod_host<cf32, cf32, cf32>(a, b, n, y); }
+int yagi_hip_dotprod_rrrf_dev(const float *a, const float *b, size_t n, float *y, yagi_stream_t s) { return dotprod_dev<float, float, float>(a, b, n, y, to_stream(s)); }
+int yagi_hip_dotprod_rccf_dev(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<float, cf32, cf32>(a, b, n, y, to_stream(s)); }
+int yagi_hip_dotprod_crcf_dev(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<cf32, float, cf32>(a, b, n, y, to_stream(s)); }
+int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<cf32, cf32, cf32>(a, b, n, y, to_stream(s)); }
+}
+
+// ---- FIR family: generic bodies, instantiated per type combination by YAGI_FIR_IMPL ----------------
+namespace yagi {
+
+template <class K>
+static int firfilt_block_host(FirFilt<K> *q, const typename K::T *x, size_t nx, typename K::T *y, size_t ny) {
+    using T = typename K::T;
+    if (nx != ny) return fail(YAGI_ERR_CONFIG, "input and output block lengths must be equal");
+    if (nx == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    YG_TRY(q->ws.x.ensure(nx * sizeof(T)));
+    YG_TRY(q->ws.y.ensure(nx * sizeof(T)));
+    YG_TRY(upload(q->ws.x.p, x, nx * sizeof(T), q->st));
+    YG_TRY(q->block_dev(q->ws.x.template as<T>(), nx, q->ws.y.template as<T>()));
+    return download(y, q->ws.y.p, nx * sizeof(T), q->st);
+}
+
+template <class K>
+static int firdecim_block_host(FirDecim<K> *q, const typename K::T *x, size_t nx, size_t n, typename K::T *y) {
+    using T = typename K::T;
+    if (n == 0) return YAGI_OK;
+    if (nx / (size_t)q->M < n) return fail(YAGI_ERR_CONFIG, "input block too short: need %zu samples, got %zu", n * (size_t)q->M, nx);
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const size_t nin = n * (size_t)q->M;
+    YG_TRY(q->ws.x.ensure(nin * sizeof(T)));
+    YG_TRY(q->ws.y.ensure(n * sizeof(T)));
+    YG_TRY(upload(q->ws.x.p, x, nin * sizeof(T), q->st));
+    YG_TRY(q->block_dev(q->ws.x.template as<T>(), n, q->ws.y.template as<T>()));
+    return download(y, q->ws.y.p, n * sizeof(T), q->st);
+}
+
+template <class K>
+static int firpfb_block_host(FirPfb<K> *q, size_t i, const typename K::T *x, size_t nx, typename K::T *y, size_t ny) {
+    using T = typename K::T;
+    YG_TRY(q->check_branch(i));
+    const size_t n = nx < ny ? nx : ny;       // zip() stops at the shorter slice (firpfb.rs:296)
+    if (n == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    YG_TRY(q->ws.x.ensure(n * sizeof(T)));
+    YG_TRY(q->ws.y.ensure(n * sizeof(T)));
+    YG_TRY(upload(q->ws.x.p, x, n * sizeof(T), q->st));
+    YG_TRY(q->block_dev(i, q->ws.x.template as<T>(), n, q->ws.y.template as<T>()));
+    return download(y, q->ws.y.p, n * sizeof(T), q->st);
+}
+
+}  // namespace yagi
+
+#define YAGI_FIR_IMPL(K, KT, T, C)                                                                  \
+    struct yagi_hip_firfilt_##K##_s : FirFilt<KT> {};                                               \
+    struct yagi_hip_firdecim_##K##_s : FirDecim<KT> {};                                             \
+    struct yagi_hip_firpfb_##K##_s : FirPfb<KT> {};                                                 \
+    extern "C" {                                                                                    \
+    int yagi_hip_firfilt_##K##_create(const C *h, size_t h_len, yagi_hip_firfilt_##K *q) {          \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_firfilt_##K##_s>();                                      \
+        YG_TRY(o->init(h, h_len));                                                                  \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_create_kaiser(size_t n, float fc, float as_, float mu,               \
+                                             yagi_hip_firfilt_##K *q) {                             \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(n, fc, as_, mu, hf));                                                  \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
+        return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_create_rect(size_t n, yagi_hip_firfilt_##K *q) {                     \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (n == 0 || n > 1024) return fail(YAGI_ERR_CONFIG, "filter length must be in [1,1024]");  \
+        std::vector<C> hc(n, one_of<C>());                                                          \
+        return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q) {                                    \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_clone(yagi_hip_firfilt_##K q, yagi_hip_firfilt_##K *out) {           \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        auto o = std::make_unique<yagi_hip_firfilt_##K##_s>();                                      \
+        o->st = q->st;                                                                              \
+        YG_TRY(o->init(q->h.data(), q->h.size()));                                                  \
+        o->scale = q->scale;                                                                        \
+        o->kernel_choice = q->kernel_choice;                                                        \
+        YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s) {                \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_set_coefficients(yagi_hip_firfilt_##K q, const C *h, size_t n) {     \
+        CHECK_Q(q);                                                                                 \
+        if (n && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        const bool resize = (n != (size_t)q->L);                                                    \
+        YG_TRY(q->load_taps(h, n));                                                                 \
+        if (resize) return q->w.init(q->L, q->st);                                                  \
+        return q->w.reset(q->st);                                                                   \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_reset(yagi_hip_firfilt_##K q) {                                      \
+        CHECK_Q(q);                                                                                 \
+        return q->w.reset(q->st);                                                                   \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_push(yagi_hip_firfilt_##K q, T x) {                                  \
+        CHECK_Q(q);                                                                                 \
+        q->w.push(x);                                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_write(yagi_hip_firfilt_##K q, const T *x, size_t n) {                \
+        CHECK_Q(q);                                                                                 \
+        if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_execute(yagi_hip_firfilt_##K q, T *y) {                              \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        return window_dot<KT>(q->w.dev(), q->taps.as<C>(), q->L, q->scale, q->ws, y, q->st);        \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_execute_one(yagi_hip_firfilt_##K q, T x, T *y) {                     \
+        CHECK_Q(q);                                                                                 \
+        q->w.push(x);                                                                               \
+        return yagi_hip_firfilt_##K##_execute(q, y);                                                \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_execute_block(yagi_hip_firfilt_##K q, const T *x, size_t nx, T *y,   \
+                                             size_t ny) {                                           \
+        CHECK_Q(q);                                                                                 \
+        return firfilt_block_host<KT>(q, x, nx, y, ny);                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_execute_block_dev(yagi_hip_firfilt_##K q, const T *x, size_t n,      \
+                                                 T *y) {                                            \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(x, n, y);                                                               \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C s) {                             \
+        CHECK_Q(q);                                                                                 \
+        q->scale = s;                                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *s) {                            \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(s);                                                                               \
+        *s = q->scale;                                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *n) {                      \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(n);                                                                               \
+        *n = (size_t)q->L;                                                                          \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_get_coefficients(yagi_hip_firfilt_##K q, C *h, size_t n) {           \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(h);                                                                               \
+        if (n < (size_t)q->L) return fail(YAGI_ERR_CONFIG, "coefficient buffer too short");         \
+        std::memcpy(h, q->h.data(), (size_t)q->L * sizeof(C));                                      \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+                                                                                                    \
+    int yagi_hip_firdecim_##K##_create(size_t M, const C *h, size_t h_len,                          \
+                                       yagi_hip_firdecim_##K *q) {                                  \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_firdecim_##K##_s>();                                     \
+        YG_TRY(o->init(M, h, h_len));                                                               \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_create_kaiser(size_t M, size_t m, float as_,                        \
+                                              yagi_hip_firdecim_##K *q) {                           \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (M < 2) return fail(YAGI_ERR_CONFIG, "decim factor must be greater than 1");             \
+        if (m == 0) return fail(YAGI_ERR_CONFIG, "filter delay must be greater than 0");            \
+        if (as_ < 0.0f) return fail(YAGI_ERR_CONFIG, "stop-band attenuation must be positive");     \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(2 * M * m + 1, 0.5f / (float)M, as_, 0.0f, hf));                       \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
+        return yagi_hip_firdecim_##K##_create(M, hc.data(), hc.size(), q);                          \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_destroy(yagi_hip_firdecim_##K q) {                                  \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_clone(yagi_hip_firdecim_##K q, yagi_hip_firdecim_##K *out) {        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        auto o = std::make_unique<yagi_hip_firdecim_##K##_s>();                                     \
+        o->st = q->st;                                                                              \
+        YG_TRY(o->init((size_t)q->M, q->h.data(), q->h.size()));                                    \
+        o->scale = q->scale;                                                                        \
+        YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_set_stream(yagi_hip_firdecim_##K q, yagi_stream_t s) {              \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_reset(yagi_hip_firdecim_##K q) {                                    \
+        CHECK_Q(q);                                                                                 \
+        return q->w.reset(q->st);                                                                   \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_get_decim_rate(yagi_hip_firdecim_##K q, size_t *M) {                \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(M);                                                                               \
+        *M = (size_t)q->M;                                                                          \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_set_scale(yagi_hip_firdecim_##K q, C s) {                           \
+        CHECK_Q(q);                                                                                 \
+        q->scale = s;                                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_get_scale(yagi_hip_firdecim_##K q, C *s) {                          \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(s);                                                                               \
+        *s = q->scale;                                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y) {     \
+        CHECK_Q(q);                                                                                 \
+        return firdecim_block_host<KT>(q, x, nx, 1, y);                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_execute_block(yagi_hip_firdecim_##K q, const T *x, size_t nx,       \
+                                              size_t n, T *y) {                                     \
+        CHECK_Q(q);                                                                                 \
+        return firdecim_block_host<KT>(q, x, nx, n, y);                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_execute_block_dev(yagi_hip_firdecim_##K q, const T *x, size_t n,    \
+                                                  T *y) {                                           \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(x, n, y);                                                               \
+    }                                                                                               \
+                                                                                                    \
+    int yagi_hip_firpfb_##K##_create(size_t nf, const C *h, size_t h_len, yagi_hip_firpfb_##K *q) { \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_firpfb_##K##_s>();                                       \
+        YG_TRY(o->init(nf, h, h_len));                                                              \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_create_kaiser(size_t nf, size_t m, float fc, float as_,               \
+                                            yagi_hip_firpfb_##K *q) {                               \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (nf == 0) return fail(YAGI_ERR_CONFIG, "number of filters must be greater than zero");   \
+        if (m == 0) return fail(YAGI_ERR_CONFIG, "filter delay must be greater than 0");            \
+        if (fc <= 0.0f || fc > 0.5f)                                                                \
+            return fail(YAGI_ERR_CONFIG, "filter cut-off frequency must be in (0,0.5)");            \
+        if (as_ < 0.0f) return fail(YAGI_ERR_CONFIG, "filter stop-band suppression must be positive"); \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(2 * nf * m + 1, fc / (float)nf, as_, 0.0f, hf));                       \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
+        return yagi_hip_firpfb_##K##_create(nf, hc.data(), hc.size(), q);                           \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_create_default(size_t nf, size_t m, yagi_hip_firpfb_##K *q) {         \
+        return yagi_hip_firpfb_##K##_create_kaiser(nf, m, 0.5f, 60.0f, q);                          \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_destroy(yagi_hip_firpfb_##K q) {                                      \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_clone(yagi_hip_firpfb_##K q, yagi_hip_firpfb_##K *out) {              \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        auto o = std::make_unique<yagi_hip_firpfb_##K##_s>();                                       \
+        o->st = q->st;                                                                              \
+        o->nf = q->nf;                                                                              \
+        o->Ls = q->Ls;                                                                              \
+        o->hb = q->hb;                                                                              \
+        o->scale = q->scale;                                                                        \
+        YG_TRY(o->taps.alloc(o->hb.size() * sizeof(C)));                                            \
+        YG_TRY(upload(o->taps.p, o->hb.data(), o->hb.size() * sizeof(C), o->st));                   \
+        YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_set_stream(yagi_hip_firpfb_##K q, yagi_stream_t s) {                  \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_reset(yagi_hip_firpfb_##K q) {                                        \
+        CHECK_Q(q);                                                                                 \
+        return q->w.reset(q->st);                                                                   \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_set_scale(yagi_hip_firpfb_##K q, C s) {                               \
+        CHECK_Q(q);                                                                                 \
+        q->scale = s;                                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_get_scale(yagi_hip_firpfb_##K q, C *s) {                              \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(s);                                                                               \
+        *s = q->scale;                                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_push(yagi_hip_firpfb_##K q, T x) {                                    \
+        CHECK_Q(q);                                                                                 \
+        q->w.push(x);                                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_write(yagi_hip_firpfb_##K q, const T *x, size_t n) {                  \
+        CHECK_Q(q);                                                                                 \
+        if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_execute(yagi_hip_firpfb_##K q, size_t i, T *y) {                      \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->check_branch(i));                                                                 \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        return window_dot<KT>(q->w.dev(), q->taps.as<C>() + i * (size_t)q->Ls, q->Ls, q->scale,     \
+                              q->ws, y, q->st);                                                     \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_execute_block(yagi_hip_firpfb_##K q, size_t i, const T *x, size_t nx, \
+                                            T *y, size_t ny) {                                      \
+        CHECK_Q(q);                                                                                 \
+        return firpfb_block_host<KT>(q, i, x, nx, y, ny);                                           \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_execute_block_dev(yagi_hip_firpfb_##K q, size_t i, const T *x,        \
+                                                size_t n, T *y) {                                   \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return q->check_branch(i);                                                      \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(i, x, n, y);                                                            \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_execute_all_dev(yagi_hip_firpfb_##K q, const T *x, size_t n, T *y) {  \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY((launch_firpfb_all<KT>(q->w.dev(), x, q->taps.as<C>(), q->nf, q->Ls, q->scale, y, n, \
+                                      q->st)));                                                     \
+        return q->w.advance(x, n, q->st);                                                           \
+    }                                                                                               \
+    int yagi_hip_firpfb_##K##_execute_select_dev(yagi_hip_firpfb_##K q, const uint32_t *idx,        \
+                                                 const T *x, size_t n, T *y) {                      \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(idx);                                                                             \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY((launch_firpfb_select<KT>(q->w.dev(), x, q->taps.as<C>(), idx, q->nf, q->Ls,         \
+                                         q->scale, y, n, q->st)));                                  \
+        return q->w.advance(x, n, q->st);                                                           \
+    }                                                                                               \
+    }
+
+YAGI_FIR_IMPL(rrrf, RRRF, float, float)
+YAGI_FIR_IMPL(crcf, CRCF, yagi_cf32, float)
+YAGI_FIR_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
+
+// crcf-only knob: which block kernel execute_block uses (0 auto, 1 general, 2 sliding)
+extern "C" int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice) {
+    CHECK_Q(q);
+    if (choice < 0 || choice > 2) return fail(YAGI_ERR_CONFIG, "unknown kernel choice %d", choice);
+    q->kernel_choice = choice;
+    return YAGI_OK;
+}
+
+// ---- Fft --------------------------------------------------------------------------------------------
+struct yagi_hip_fft_s : FftPlan {};
+
+extern "C" {
+
+int yagi_hip_fft_create(size_t n, int direction, yagi_hip_fft *plan) {
+    CHECK_PTR(plan);
+    *plan = nullptr;
+    auto p = std::make_unique<yagi_hip_fft_s>();
+    YG_TRY(fft_plan_init(*p, n, direction));
+    *plan = p.release();
+    return YAGI_OK;
+}
+int yagi_hip_fft_destroy(yagi_hip_fft plan) { delete plan; return YAGI_OK; }
+int yagi_hip_fft_clone(yagi_hip_fft plan, yagi_hip_fft *out) {
+    CHECK_Q(plan);
+    return yagi_hip_fft_create((size_t)plan->d.n, plan->d.dir, out);
+}
+int yagi_hip_fft_len(yagi_hip_fft plan, size_t *n) {
+    CHECK_Q(plan);
+    CHECK_PTR(n);
+    *n = (size_t)plan->d.n;
+    return YAGI_OK;
+}
+int yagi_hip_fft_run_batch_dev(yagi_hip_fft plan, const yagi_cf32 *in, yagi_cf32 *out, size_t batch,
+                               yagi_stream_t s) {
+    CHECK_Q(plan);
+    if (batch == 0) return YAGI_OK;
+    CHECK_PTR(in);
+    CHECK_PTR(out);
+    return launch_fft_batch(plan->d, in, out, batch, to_stream(s));
+}
+int yagi_hip_fft_run(yagi_hip_fft plan, const yagi_cf32 *input, size_t n_in, yagi_cf32 *output, size_t n_out) {
+    CHECK_Q(plan);
+    const size_t n = (size_t)plan->d.n;
+    // the reference panics on a length mismatch (copy_from_slice, fft/mod.rs:46)
+    if (n_in != n || n_out != n) return fail(YAGI_ERR_CONFIG, "fft buffers must hold exactly %zu samples", n);
+    CHECK_PTR(input);
+    CHECK_PTR(output);
+    YG_TRY(plan->ws.x.ensure(n * sizeof(cf32)));
+    YG_TRY(plan->ws.y.ensure(n * sizeof(cf32)));
+    YG_TRY(upload(plan->ws.x.p, input, n * sizeof(cf32), nullptr));
+    YG_TRY(launch_fft_batch(plan->d, plan->ws.x.as<cf32>(), plan->ws.y.as<cf32>(), 1, nullptr));
+    return download(output, plan->ws.y.p, n * sizeof(cf32), nullptr);
+}
+int yagi_hip_fft_shift_dev(yagi_cf32 *buf, size_t n, size_t batch, yagi_stream_t s) {
+    if (n == 0 || batch == 0) return YAGI_OK;
+    CHECK_PTR(buf);
+    YG_TRY(require_device());
+    return launch_fft_shift(buf, n, batch, to_stream(s));
+}
+int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n) {
+    if (n < 2) return YAGI_OK;
+    CHECK_PTR(buf);
+    YG_TRY(require_device());
+    DevBuf d;
+    YG_TRY(d.alloc(n * sizeof(cf32)));
+    YG_TRY(upload(d.p, buf, n * sizeof(cf32), nullptr));
+    YG_TRY(launch_fft_shift(d.as<cf32>(), n, 1, nullptr));
+    return download(buf, d.p, n * sizeof(cf32), nullptr);
+}
+int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n, int direction) {
+    yagi_hip_fft p = nullptr;
+    YG_TRY(yagi_hip_fft_create(n, direction, &p));
+    int rc = yagi_hip_fft_run(p, input, n, output, n);
+    yagi_hip_fft_destroy(p);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---- fused firfilt_crcf -> FFT stream ------------------------------------------------------------------
+struct yagi_hip_firfft_crcf_s : FirFft {};
+
+extern "C" {
+
+int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_hip_firfft_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");
+    if (nfft != 4096) return fail(YAGI_ERR_CONFIG, "fused stream supports nfft = 4096 (got %zu)", nfft);
+    auto o = std::make_unique<yagi_hip_firfft_crcf_s>();
+    YG_TRY(o->fir.init(h, h_len));
+    if (o->fir.Lp > kSlideMaxTaps) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%zu taps)", h_len);
+    o->nfft = nfft;
+    YG_TRY(make_twiddles((int)nfft, YAGI_FFT_FORWARD, o->tw));
+    *q = o.release();
+    return YAGI_OK;
+}
+int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) { delete q; return YAGI_OK; }
+int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s) {
+    CHECK_Q(q);
+    YG_HIP(hipStreamSynchronize(q->fir.st));
+    q->fir.st = to_stream(s);
+    return YAGI_OK;
+}
+int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) { CHECK_Q(q); q->fir.scale = scale; return YAGI_OK; }
+int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->fir.w.reset(q->fir.st); }
+int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
+    CHECK_Q(q);
+    if (variant < 0 || variant > 2) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    q->variant = variant;
+    return YAGI_OK;
+}
+int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(spectra);
+    auto &f = q->fir;
+    YG_TRY(f.w.flush(f.st));
+    YG_TRY(launch_firfft_crcf_4096(f.w.dev(), x, f.taps_pad.as<float>(), nullptr, f.L, f.Lp, f.scale,
+                                   q->tw.as<cf32>(), spectra, nframes, q->variant, f.st));
+    return f.w.advance(x, nframes * q->nfft, f.st);
+}
+int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(spectra);
+    const size_t bytes = nframes * q->nfft * sizeof(cf32);
+    YG_TRY(q->xin.ensure(bytes));
+    YG_TRY(q->yout.ensure(bytes));
+    YG_TRY(upload(q->xin.p, x, bytes, q->fir.st));
+    YG_TRY(yagi_hip_firfft_crcf_execute_dev(q, q->xin.as<cf32>(), nframes, q->yout.as<cf32>()));
+    return download(spectra, q->yout.p, bytes, q->fir.st);
+}
+
+}  // extern "C"
+
+// ---- channelizers ------------------------------------------------------------------------------------
+struct yagi_hip_firpfbch_crcf_s : PfbCh {};
+struct yagi_hip_firpfbch2_crcf_s : PfbCh2 {};
+
+extern "C" {
+
+int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_firpfbch_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (M == 0) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than zero");
+    if (p == 0) return fail(YAGI_ERR_CONFIG, "invalid filter size (must be greater than 0)");
+    CHECK_PTR(h);
+    if (M > 8192 || p > 4096) return fail(YAGI_ERR_CONFIG, "channelizer too large");
+    YG_TRY(require_device());
+    auto o = std::make_unique<yagi_hip_firpfbch_crcf_s>();
+    o->M = (int)M;
+    o->p = (int)p;
+    YG_TRY(o->h.alloc(M * p * sizeof(float)));
+    YG_TRY(upload(o->h.p, h, M * p * sizeof(float), nullptr));
+    YG_TRY(make_twiddles((int)M, YAGI_FFT_FORWARD, o->tw));
+    const size_t hl = (p - 1) * M;
+    YG_TRY(o->hist.init((int)(hl ? hl : 1), nullptr));
+    *q = o.release();
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (M == 0) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than zero");
+    if (m == 0) return fail(YAGI_ERR_CONFIG, "invalid filter size (must be greater than 0)");
+    std::vector<float> hf;
+    YG_TRY(design_kaiser(2 * M * m + 1, 0.5f / (float)M, std::fabs(as_), 0.0f, hf));
+    return yagi_hip_firpfbch_crcf_create(M, 2 * m, hf.data(), q);
+}
+int yagi_hip_firpfbch_crcf_destroy(yagi_hip_firpfbch_crcf q) { delete q; return YAGI_OK; }
+int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s) {
+    CHECK_Q(q);
+    YG_HIP(hipStreamSynchronize(q->st));
+    q->st = to_stream(s);
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q) { CHECK_Q(q); return q->hist.reset(q->st); }
+int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    // a p == 1 channelizer has no history; the 1-sample placeholder window is never read
+    YG_TRY(launch_firpfbch(q->hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st));
+    if (q->p > 1) return q->hist.advance(x, nframes * (size_t)q->M, q->st);
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const size_t bytes = nframes * (size_t)q->M * sizeof(cf32);
+    YG_TRY(q->ws.x.ensure(bytes));
+    YG_TRY(q->ws.y.ensure(bytes));
+    YG_TRY(upload(q->ws.x.p, x, bytes, q->st));
+    YG_TRY(yagi_hip_firpfbch_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nframes, q->ws.y.as<cf32>()));
+    return download(y, q->ws.y.p, bytes, q->st);
+}
+
+int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
+    if (m < 1) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 1");
+    CHECK_PTR(h);
+    if (M > 8192 || m > 2048) return fail(YAGI_ERR_CONFIG, "channelizer too large");
+    YG_TRY(require_device());
+    auto o = std::make_unique<yagi_hip_firpfbch2_crcf_s>();
+    o->M = (int)M;
+    o->m = (int)m;
+    const size_t hl = 2 * M * m;
+    YG_TRY(o->h.alloc(hl * sizeof(float)));
+    YG_TRY(upload(o->h.p, h, hl * sizeof(float), nullptr));
+    YG_TRY(make_twiddles((int)M, YAGI_FFT_FORWARD, o->tw));
+    YG_TRY(o->hist.init((int)((2 * m - 1) * M + M / 2), nullptr));
+    *q = o.release();
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
+    if (m < 1) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 1");
+    std::vector<float> hf;
+    YG_TRY(design_kaiser(2 * M * m + 1, 1.0f / (float)M, std::fabs(as_), 0.0f, hf));
+    float hsum = 0.0f;                          // normalise to unit channel gain: sum(h) = M
+    for (float v : hf) hsum += v;
+    for (float &v : hf) v = v * (float)M / hsum;
+    return yagi_hip_firpfbch2_crcf_create(M, m, hf.data(), q);
+}
+int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q) { delete q; return YAGI_OK; }
+int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s) {
+    CHECK_Q(q);
+    YG_HIP(hipStreamSynchronize(q->st));
+    q->st = to_stream(s);
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q) {
+    CHECK_Q(q);
+    q->step = 0;
+    return q->hist.reset(q->st);
+}
+int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps,
+                                                       int rank, int nranks, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    YG_TRY(launch_firpfbch2(q->hist.dev(), q->hist.len, x, q->h.as<float>(), q->M, q->m, q->tw.as<cf32>(),
+                            q->step, rank, nranks, y, nsteps, q->st));
+    q->step += nsteps;
+    return q->hist.advance(x, nsteps * (size_t)(q->M / 2), q->st);
+}
+int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+    return yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(q, x, nsteps, 0, 1, y);
+}
+int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const size_t bin = nsteps * (size_t)(q->M / 2) * sizeof(cf32), bout = nsteps * (size_t)q->M * sizeof(cf32);
+    YG_TRY(q->ws.x.ensure(bin));
+    YG_TRY(q->ws.y.ensure(bout));
+    YG_TRY(upload(q->ws.x.p, x, bin, q->st));
+    YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nsteps, q->ws.y.as<cf32>()));
+    return download(y, q->ws.y.p, bout, q->st);
+}
+int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered, size_t nsteps, size_t M, int nranks,
+                                         yagi_cf32 *y, yagi_stream_t s) {
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(gathered);
+    CHECK_PTR(y);
+    return launch_firpfbch2_assemble(gathered, nsteps, (int)M, nranks, y, to_stream(s));
+}
+
+}  // extern "C"

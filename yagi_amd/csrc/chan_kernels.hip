@@ -1,0 +1,279 @@
+// chan_kernels.hip -- polyphase channelizers multichannel::firpfbch / firpfbch2 (analyzers).
+//
+// The reference module is EMPTY (src/multichannel/mod.rs, 0 lines; LIQUID_COMPAT.md:1765-1798),
+// so these kernels implement liquid-dsp's published semantics composed from the reference's own
+// pieces: the FirPfb branch split h_i[n] = h[i + n*M] (firpfb.rs:45-52), Window state
+// (window.rs:77-85), dotprod (dotprod/mod.rs:33-45) and the unnormalised DFT of Fft
+// (fft/mod.rs:19-26).  See oracle/yagi_oracle.c for the sequential restatement they are tested
+// against (parity unpinned by the reference; property tests in tests/test_chan_*.py).
+//
+// Closed forms used here (X = hist ++ x, X[0] = x[0], f = frame / s = step index of this call):
+//   firpfbch  : V[f][c] = sum_{n<p} h[(M-1-c) + n*M] * X[(f-n)*M + c]          c in [0,M)
+//               y[f][k] = sum_c V[f][c] e^{-j 2 pi c k / M}
+//   firpfbch2 : window b is fed on steps of parity (b >= M/2), at position
+//               pos_b = (b < M/2 ? M/2-1-b : M-1-b); with s_b = latest such step <= s and
+//               i = (b - (s odd ? M/2 : 0)) mod M:
+//               V[s][b] = sum_{n<2m} h[i + n*M] * X[s_b*M/2 + pos_b - n*M]
+//               y[s][k] = (1/M) sum_b V[s][b] e^{+j 2 pi b k / M}
+//   sharded   : rank r of R keeps k = r + R*q:  fold Z[b'] = e^{+j2pi b' r/M} sum_a e^{+j2pi a r/R}
+//               V[(M/R)a + b'], then an (M/R)-point inverse DFT over b' (decimation in frequency),
+//               so each GPU writes only M/R outputs per step.
+// One workgroup owns a tile of frames: input tile + history staged in LDS once (8 B/sample from
+// HBM), branch dot products from LDS, the M-point DFTs as Stockham passes in LDS, coalesced
+// [frame][channel] stores (8 or 16 B per input sample).  HBM-bound by construction.
+#include "devmath.hpp"
+#include "kernels.hpp"
+
+namespace yagi {
+
+struct FacList { int n; int f[16]; };
+
+static FacList factorize_small(int n) {
+    FacList L{0, {0}};
+    while (n % 4 == 0) { L.f[L.n++] = 4; n /= 4; }
+    for (int p : {2, 3, 5, 7}) while (n % p == 0) { L.f[L.n++] = p; n /= p; }
+    for (int p = 11; n > 1 && L.n < 15; p += 2) while (n % p == 0 && L.n < 15) { L.f[L.n++] = p; n /= p; }
+    if (n > 1) L.f[L.n++] = n;
+    return L;
+}
+
+// nfr independent N-point DFTs stored [frame][N] in LDS buffer `src`; result buffer returned.
+// tw = W_Mtab^m table (forward sign), N * tw_scale == Mtab; conj => inverse transform.
+__device__ __forceinline__ float2 *lds_dft_frames(float2 *src, float2 *dst, int N, int nfr,
+                                                  const FacList &fl, const float2 *__restrict__ tw,
+                                                  int tw_scale, bool conj) {
+    int Ns = 1;
+    const int total = N * nfr;
+    for (int f = 0; f < fl.n; ++f) {
+        const int R = fl.f[f];
+        const int T = N / R;
+        const int tw_k = N / (Ns * R);
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int fr = e / N, idx = e - fr * N;
+            const int q = idx / T, j = idx - q * T;
+            const int k = j % Ns;
+            const int step = (k * tw_k + q * T) % N;
+            const float2 *s = src + fr * N;
+            float2 acc = s[j];
+            int m = 0;
+            for (int r = 1; r < R; ++r) {
+                m += step;
+                if (m >= N) m -= N;
+                float2 w = tw[m * tw_scale];
+                if (conj) w.y = -w.y;
+                acc = cadd(acc, cmul(s[j + r * T], w));
+            }
+            dst[fr * N + (j / Ns) * Ns * R + k + q * Ns] = acc;
+        }
+        __syncthreads();
+        float2 *t = src; src = dst; dst = t;
+        Ns *= R;
+    }
+    return src;
+}
+
+__device__ __forceinline__ float2 load_hist(const float2 *__restrict__ hist, int hist_len,
+                                            const float2 *__restrict__ x, long long idx, long long x_len) {
+    if (idx >= 0) return (idx < x_len) ? x[idx] : make_float2(0.f, 0.f);
+    const long long h = hist_len + idx;
+    return (h >= 0) ? hist[h] : make_float2(0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// firpfbch analyzer
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                const float *__restrict__ h, int M, int p, const float2 *__restrict__ twM,
+                FacList fl, float2 *__restrict__ y, size_t nframes, int F) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *xs = reinterpret_cast<float2 *>(smem);              // (F + p - 1) * M samples
+    float2 *va = xs + (size_t)(F + p - 1) * M;                  // F * M
+    float2 *vb = va + (size_t)F * M;                            // F * M
+    const int hist_len = (p - 1) * M;
+    for (size_t tile = blockIdx.x; tile * F < nframes; tile += gridDim.x) {
+        const size_t f0 = tile * F;
+        const int nf = (int)((nframes - f0) < (size_t)F ? (nframes - f0) : (size_t)F);
+        const long long base = (long long)f0 * M - hist_len;
+        const int nspan = (nf + p - 1) * M;
+        for (int u = threadIdx.x; u < nspan; u += 256)
+            xs[u] = load_hist(hist, hist_len, x, base + u, (long long)nframes * M);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nf * M; e += 256) {
+            const int f = e / M, c = e - f * M;
+            float2 acc = make_float2(0.f, 0.f);
+            // X[(f0+f-n)*M + c] sits at span offset (f + p-1 - n)*M + c
+            for (int n = 0; n < p; ++n) {
+                const float hv = h[(M - 1 - c) + n * M];
+                const float2 s = xs[(f + p - 1 - n) * M + c];
+                acc.x = fmaf(s.x, hv, acc.x);
+                acc.y = fmaf(s.y, hv, acc.y);
+            }
+            va[e] = acc;
+        }
+        __syncthreads();
+        float2 *res = lds_dft_frames(va, vb, M, nf, fl, twM, 1, false);
+        for (int e = threadIdx.x; e < nf * M; e += 256) y[f0 * M + e] = res[e];
+        __syncthreads();
+    }
+}
+
+static constexpr size_t kChanLdsBudget = 60 * 1024;
+
+int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
+                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
+    if (nframes == 0) return YAGI_OK;
+    // frames per tile: as many as fit the LDS budget (>= 1)
+    int F = 4096 / M;
+    if (F < 1) F = 1;
+    auto need = [&](int f) { return ((size_t)(f + p - 1) * M + 2 * (size_t)f * M) * sizeof(float2); };
+    while (F > 1 && need(F) > kChanLdsBudget) F /= 2;
+    if (need(F) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch: M*p too large for LDS (%d x %d)", M, p);
+    static bool raised = false;
+    if (need(F) > 64 * 1024 && !raised) {
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const size_t tiles = (nframes + F - 1) / F;
+    const unsigned grid = (unsigned)(tiles < 65536 ? tiles : 65536);
+    firpfbch_kernel<<<grid, 256, need(F), st>>>(reinterpret_cast<const float2 *>(hist),
+                                               reinterpret_cast<const float2 *>(x), h, M, p,
+                                               reinterpret_cast<const float2 *>(twM),
+                                               factorize_small(M), reinterpret_cast<float2 *>(y),
+                                               nframes, F);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// firpfbch2 analyzer (optionally one rank's sub-band shard)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
+                 const float *__restrict__ h, int M, int p, const float2 *__restrict__ twM,
+                 FacList fl, unsigned long long step0, int rank, int R,
+                 float2 *__restrict__ y, size_t nsteps, int S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int M2 = M / 2, Mr = M / R;
+    const int lead = (p - 1) * M + M2;                         // samples needed before a tile
+    float2 *xs = reinterpret_cast<float2 *>(smem);             // lead + S*M2 samples
+    float2 *va = xs + (size_t)lead + (size_t)S * M2;           // S * M
+    float2 *vb = va + (size_t)S * M;                           // S * Mr (fold) / Stockham partner
+    const float invM = 1.0f / (float)M;
+    const long long x_len = (long long)nsteps * M2;
+    for (size_t tile = blockIdx.x; tile * S < nsteps; tile += gridDim.x) {
+        const size_t s0 = tile * S;
+        const int ns = (int)((nsteps - s0) < (size_t)S ? (nsteps - s0) : (size_t)S);
+        const long long base = (long long)s0 * M2 - lead;
+        const int nspan = lead + ns * M2;
+        for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = load_hist(hist, hist_len, x, base + u, x_len);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ns * M; e += 256) {
+            const int sl = e / M, b = e - sl * M;
+            const unsigned long long sg = step0 + s0 + sl;     // global step index (parity = flag)
+            const int flag = (int)(sg & 1ull);
+            const int bpar = (b >= M2) ? 1 : 0;
+            const int pos = bpar ? (M - 1 - b) : (M2 - 1 - b);
+            const int back = (flag == bpar) ? 0 : 1;           // steps since window b was last fed
+            int i = b - (flag ? M2 : 0);
+            if (i < 0) i += M;
+            // newest sample of window b: local step (sl - back), span offset lead + (sl-back)*M2 + pos
+            const int top = lead + (sl - back) * M2 + pos;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int n = 0; n < p; ++n) {
+                const float hv = h[i + n * M];
+                const float2 s = xs[top - n * M];
+                acc.x = fmaf(s.x, hv, acc.x);
+                acc.y = fmaf(s.y, hv, acc.y);
+            }
+            va[e] = acc;
+        }
+        __syncthreads();
+        float2 *srcb = va, *dstb = vb;
+        if (R > 1) {
+            // fold to the rank's residue class: Z[b'] = W_M^{-b' r} sum_a W_R^{-a r} V[Mr*a + b']
+            for (int e = threadIdx.x; e < ns * Mr; e += 256) {
+                const int sl = e / Mr, bq = e - sl * Mr;
+                float2 acc = make_float2(0.f, 0.f);
+                for (int a = 0; a < R; ++a) {
+                    float2 w = twM[((a * rank) % R) * Mr];     // W_R^{a r} = W_M^{a r M/R}
+                    w.y = -w.y;
+                    acc = cadd(acc, cmul(va[sl * M + Mr * a + bq], w));
+                }
+                float2 w2 = twM[(bq * rank) % M];
+                w2.y = -w2.y;
+                vb[e] = cmul(acc, w2);
+            }
+            __syncthreads();
+            srcb = vb;
+            dstb = va;
+        }
+        float2 *res = lds_dft_frames(srcb, dstb, Mr, ns, fl, twM, R, true);
+        for (int e = threadIdx.x; e < ns * Mr; e += 256) {
+            const float2 v = res[e];
+            y[s0 * Mr + e] = make_float2(v.x * invM, v.y * invM);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
+                     const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
+                     hipStream_t st) {
+    if (nsteps == 0) return YAGI_OK;
+    const int p = 2 * m, M2 = M / 2;
+    if (nranks < 1 || M % nranks || rank < 0 || rank >= nranks)
+        return fail(YAGI_ERR_CONFIG, "firpfbch2: %d channels do not shard over %d ranks", M, nranks);
+    const size_t lead = (size_t)(p - 1) * M + M2;
+    if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
+    int S = 4096 / M;
+    if (S < 1) S = 1;
+    auto need = [&](int s) { return (lead + (size_t)s * M2 + 2 * (size_t)s * M) * sizeof(float2); };
+    while (S > 1 && need(S) > kChanLdsBudget) S /= 2;
+    if (need(S) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch2: M*m too large for LDS (%d x %d)", M, m);
+    static bool raised = false;
+    if (need(S) > 64 * 1024 && !raised) {
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const size_t tiles = (nsteps + S - 1) / S;
+    const unsigned grid = (unsigned)(tiles < 65536 ? tiles : 65536);
+    firpfbch2_kernel<<<grid, 256, need(S), st>>>(reinterpret_cast<const float2 *>(hist), hist_len,
+                                                reinterpret_cast<const float2 *>(x), h, M, p,
+                                                reinterpret_cast<const float2 *>(twM),
+                                                factorize_small(M / nranks), (unsigned long long)step0,
+                                                rank, nranks, reinterpret_cast<float2 *>(y), nsteps, S);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+// gathered[rank][step][q]  ->  y[step][rank + nranks*q]
+__global__ void __launch_bounds__(256)
+assemble_kernel(const float2 *__restrict__ g, size_t nsteps, int M, int R, float2 *__restrict__ y) {
+    const int Mr = M / R;
+    const size_t total = nsteps * (size_t)M;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = e / M;
+        const int k = (int)(e - s * M);
+        const int r = k % R, q = k / R;
+        y[e] = g[((size_t)r * nsteps + s) * Mr + q];
+    }
+}
+
+int launch_firpfbch2_assemble(const cf32 *gathered, size_t nsteps, int M, int nranks, cf32 *y,
+                              hipStream_t st) {
+    const size_t total = nsteps * (size_t)M;
+    if (total == 0) return YAGI_OK;
+    if (nranks < 1 || M % nranks) return fail(YAGI_ERR_CONFIG, "assemble: bad nranks");
+    size_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    assemble_kernel<<<(unsigned)g, 256, 0, st>>>(reinterpret_cast<const float2 *>(gathered), nsteps, M,
+                                                nranks, reinterpret_cast<float2 *>(y));
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+}  // namespace yagi

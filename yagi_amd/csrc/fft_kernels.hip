@@ -1,0 +1,129 @@
+// fft_kernels.hip -- batched complex FFT, Fft::run semantics (src/fft/mod.rs:39-57; the
+// reference's arithmetic is the external crate rustfft 6.2, so this is a from-scratch engine
+// for the same definition: unnormalised DFT, forward = e^{-j 2 pi n k / N}).
+//
+//   fft4096_kernel   config C3 (4096-pt x 65 536): one workgroup per transform, data makes one
+//                    HBM round trip (64 KiB per transform = 16 B/point), everything else in
+//                    registers + 34 KiB LDS (fft_core.hpp).
+//   fft_lds_kernel   any N <= 8192: Stockham autosort passes in LDS over the plan's factor list;
+//                    each lane produces ONE output of a radix-R butterfly per pass by a direct
+//                    R-term sum with exact table twiddles (index arithmetic mod N), so every
+//                    radix, prime or not, takes the same code path (O(N * sum(R)) work).
+#include "fft_core.hpp"
+#include "kernels.hpp"
+
+namespace yagi {
+
+template <int SIGN>
+__global__ void __launch_bounds__(256)
+fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+               const float2 *__restrict__ tw, size_t batch) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        const float2 *src = in + b * 4096;
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = src[256 * a + threadIdx.x];
+        fft4096_passes<SIGN>(v, lds, tw, out + b * 4096);
+    }
+}
+
+// Stockham pass structure (Ns = product of the radices already applied, T = N / R):
+//   butterfly j in [0,T), k = j mod Ns, output q in [0,R):
+//     out[(j / Ns) * Ns * R + k + q * Ns] = sum_r in[j + r*T] * W_N^{ r * (k*N/(Ns*R) + q*N/R) }
+__global__ void __launch_bounds__(256)
+fft_lds_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__ out, size_t batch) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *bufA = reinterpret_cast<float2 *>(smem);
+    float2 *bufB = bufA + p.n;
+    const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
+    const int N = p.n;
+    for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) bufA[i] = in[b * N + i];
+        __syncthreads();
+        float2 *src = bufA, *dst = bufB;
+        int Ns = 1;
+        for (int f = 0; f < p.nfac; ++f) {
+            const int R = p.fac[f];
+            const int T = N / R;
+            const int tw_k = N / (Ns * R);        // W_{Ns*R} = W_N^{tw_k}
+            for (int idx = threadIdx.x; idx < N; idx += blockDim.x) {
+                const int q = idx / T, j = idx - q * T;
+                const int k = j % Ns;
+                // step = (k*tw_k + q*T) mod N, kept < N; the twiddle index advances by `step` per term
+                int step = (int)(((long long)k * tw_k + (long long)q * T) % N);
+                int m = 0;
+                float2 acc = src[j];
+                for (int r = 1; r < R; ++r) {
+                    m += step;
+                    if (m >= N) m -= N;
+                    acc = cadd(acc, cmul(src[j + r * T], tw[m]));
+                }
+                dst[(j / Ns) * Ns * R + k + q * Ns] = acc;
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+            Ns *= R;
+        }
+        for (int i = threadIdx.x; i < N; i += blockDim.x) out[b * N + i] = src[i];
+        __syncthreads();
+    }
+}
+
+int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    if (batch == 0) return YAGI_OK;
+    const float2 *fin = reinterpret_cast<const float2 *>(in);
+    float2 *fout = reinterpret_cast<float2 *>(out);
+    const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
+    if (p.n == 4096) {
+        const unsigned grid = (unsigned)(batch < 65536 ? batch : 65536);
+        if (p.dir == YAGI_FFT_FORWARD)
+            fft4096_kernel<-1><<<grid, 256, 0, st>>>(fin, fout, tw, batch);
+        else
+            fft4096_kernel<+1><<<grid, 256, 0, st>>>(fin, fout, tw, batch);
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
+    if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
+    const size_t lds = 2 * (size_t)p.n * sizeof(float2);
+    const unsigned grid = (unsigned)(batch < 16384 ? batch : 16384);
+    int threads = 256;
+    if (p.n < 256) threads = ((p.n + 63) / 64) * 64;
+    if (lds > 64 * 1024) {
+        static bool raised = false;            // one-time opt-in to >64 KiB dynamic LDS
+        if (!raised) {
+            YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    fft_lds_kernel<<<grid, threads, lds, st>>>(p, fin, fout, batch);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+// Fft::shift (fft/mod.rs:50-57): swap the two halves; for odd n the last element stays.
+__global__ void __launch_bounds__(256) fft_shift_kernel(float2 *buf, size_t n, size_t batch) {
+    const size_t n2 = n / 2;       // (n-1)/2 for odd n == n/2 in integer arithmetic
+    const size_t total = n2 * batch;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / n2, i = e - b * n2;
+        float2 *v = buf + b * n;
+        const float2 t = v[i];
+        v[i] = v[i + n2];
+        v[i + n2] = t;
+    }
+}
+
+int launch_fft_shift(cf32 *buf, size_t n, size_t batch, hipStream_t st) {
+    const size_t total = (n / 2) * batch;
+    if (total == 0) return YAGI_OK;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    fft_shift_kernel<<<(unsigned)g, 256, 0, st>>>(reinterpret_cast<float2 *>(buf), n, batch);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+}  // namespace yagi

@@ -1,0 +1,230 @@
+// fir_kernels.hip -- direct-form FIR kernels for all three type combinations:
+//   FirFilter::execute_block        (src/filter/fir/firfilt.rs:267-278)      M = 1
+//   FirDecimationFilter::execute_block (src/filter/fir/firdecim.rs:179-205)  stride M
+//   FirPfbFilter branch forms       (src/filter/fir/firpfb.rs:255-301)
+//
+// Data layout in HBM: samples contiguous (interleaved {re,im} for complex), taps h[0..L) in
+// natural order, the filter state ("window") = the L samples preceding x[0], oldest first
+// (what Window::read() returns, window.rs:66-68).  X below is the virtual stream win ++ x with
+// X[0] = x[0]; the kernels never materialise it.
+//
+// fir_block_kernel: one workgroup produces `tile` consecutive outputs.  It stages the input
+// span ((tile-1)*M + L samples, coalesced) and the taps in LDS, then every lane accumulates R
+// outputs that are 256 apart, so at tap k the wave reads 64 consecutive samples (conflict-free
+// ds_read) and one broadcast tap.  Algorithmic HBM traffic: sizeof(T)*(M + 1) bytes per output
+// (+ the (L-1)-sample halo per tile, which is L2-resident).  This is the general kernel (any
+// L, M, type); the crcf M=1 hot case has an MFMA version in fir_mfma.hip.
+#include "devmath.hpp"
+#include "kernels.hpp"
+
+namespace yagi {
+
+constexpr int kFirBlock = 256;
+constexpr int kFirR = 4;                         // outputs per lane
+constexpr size_t kFirLdsBudget = 48 * 1024;
+
+template <class T>
+__device__ __forceinline__ T load_stream(const T *__restrict__ win, const T *__restrict__ x,
+                                         long long idx, int L) {
+    return (idx < 0) ? win[L + idx] : x[idx];
+}
+
+template <class K, bool STAGE>
+__global__ void __launch_bounds__(kFirBlock)
+fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                 const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
+                 typename K::T *__restrict__ y, size_t ny, int tile) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const size_t o0 = (size_t)blockIdx.x * (size_t)tile;
+    const int nt = (int)((ny - o0) < (size_t)tile ? (ny - o0) : (size_t)tile);
+    const long long base = (long long)o0 * M - (L - 1);
+    const int span = (nt - 1) * M + L;
+
+    T *xs = reinterpret_cast<T *>(smem);
+    C *hs = reinterpret_cast<C *>(smem + (STAGE ? (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 : 0));
+    if (STAGE) {
+        for (int i = threadIdx.x; i < span; i += kFirBlock) xs[i] = load_stream(win, x, base + i, L);
+    }
+    for (int k = threadIdx.x; k < L; k += kFirBlock) hs[k] = taps[k];
+    __syncthreads();
+
+    T acc[kFirR];
+#pragma unroll
+    for (int r = 0; r < kFirR; ++r) acc[r] = zero_of<T>();
+
+    // newest sample of output o sits at span offset o*M + (L-1)
+    for (int k = 0; k < L; ++k) {
+        const C hk = hs[k];
+#pragma unroll
+        for (int r = 0; r < kFirR; ++r) {
+            const int o = threadIdx.x + r * kFirBlock;
+            if (o < nt) {
+                const int off = o * M + (L - 1) - k;
+                const T xv = STAGE ? xs[off] : load_stream(win, x, base + off, L);
+                acc[r] = mac(acc[r], xv, hk);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kFirR; ++r) {
+        const int o = threadIdx.x + r * kFirBlock;
+        if (o < nt) y[o0 + o] = mul(acc[r], scale);
+    }
+}
+
+template <class K>
+int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
+                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+    using T = typename K::T;
+    using C = typename K::C;
+    if (ny == 0) return YAGI_OK;
+    if (L <= 0 || M <= 0) return fail(YAGI_ERR_INTERNAL, "fir_block: bad L/M");
+    // largest tile (<= R*256 outputs) whose span + taps fit the LDS budget
+    const size_t tap_bytes = (size_t)L * sizeof(C);
+    int tile = kFirR * kFirBlock;
+    bool stage = true;
+    while (tile >= 64) {
+        const size_t need = (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 + tap_bytes;
+        if (need <= kFirLdsBudget) break;
+        tile /= 2;
+    }
+    size_t lds;
+    if (tile < 64) {           // taps/span too large for LDS staging: stream from L2/HBM
+        if (tap_bytes > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "filter too long for this engine (%d taps)", L);
+        stage = false;
+        tile = kFirR * kFirBlock;
+        lds = tap_bytes;
+    } else {
+        lds = (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 + tap_bytes;
+    }
+    const size_t nblk = (ny + tile - 1) / tile;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    if (stage)
+        fir_block_kernel<K, true><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile);
+    else
+        fir_block_kernel<K, false><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+template int launch_fir_block<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t);
+template int launch_fir_block<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t);
+template int launch_fir_block<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// polyphase bank, all branches per pushed sample (interpolator form):
+//   y[n*nf + i] = scale * sum_{k<Ls} hb[i][k] * X[n-k]
+// A workgroup owns TN consecutive input samples x all nf branches.  Samples + halo are staged
+// in LDS; branch taps are staged TRANSPOSED (hsT[k][i]) so the 64 lanes of a wave, which hold
+// 64 consecutive branches i, read consecutive LDS words; stores are coalesced along i.
+// Traffic: sizeof(T) read + nf*sizeof(T) written per input sample (write-bound).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPfbTN = 64;
+
+template <class K, bool TAPS_LDS>
+__global__ void __launch_bounds__(256)
+firpfb_all_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                  const typename K::C *__restrict__ hb, int nf, int Ls, typename K::C scale,
+                  typename K::T *__restrict__ y, size_t n) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);                       // kPfbTN + Ls - 1 samples
+    C *hsT = reinterpret_cast<C *>(smem + ((size_t)(kPfbTN + Ls - 1) * sizeof(T) + 15) / 16 * 16);
+    const size_t n0 = (size_t)blockIdx.x * kPfbTN;
+    const int nt = (int)((n - n0) < (size_t)kPfbTN ? (n - n0) : (size_t)kPfbTN);
+    const long long base = (long long)n0 - (Ls - 1);
+    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    if (TAPS_LDS)
+        for (int e = threadIdx.x; e < nf * Ls; e += 256) {
+            const int i = e / Ls, k = e - i * Ls;
+            hsT[k * nf + i] = hb[e];
+        }
+    __syncthreads();
+    const int total = nt * nf;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int nl = e / nf, i = e - nl * nf;
+        T acc = zero_of<T>();
+        for (int k = 0; k < Ls; ++k) {
+            const C hk = TAPS_LDS ? hsT[k * nf + i] : hb[i * Ls + k];
+            acc = mac(acc, xs[nl + (Ls - 1) - k], hk);
+        }
+        y[(n0 + nl) * (size_t)nf + i] = mul(acc, scale);
+    }
+}
+
+template <class K>
+int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
+                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st) {
+    using T = typename K::T;
+    using C = typename K::C;
+    if (n == 0) return YAGI_OK;
+    const size_t xs_bytes = ((size_t)(kPfbTN + Ls - 1) * sizeof(T) + 15) / 16 * 16;
+    if (xs_bytes > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "branch filters too long (%d taps)", Ls);
+    const size_t tap_bytes = (size_t)nf * Ls * sizeof(C);
+    const bool taps_lds = xs_bytes + tap_bytes <= kFirLdsBudget;
+    const size_t nblk = (n + kPfbTN - 1) / kPfbTN;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    if (taps_lds)
+        firpfb_all_kernel<K, true><<<(unsigned)nblk, 256, xs_bytes + tap_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n);
+    else
+        firpfb_all_kernel<K, false><<<(unsigned)nblk, 256, xs_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+template int launch_firpfb_all<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t);
+template int launch_firpfb_all<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t);
+template int launch_firpfb_all<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// branch index per sample (the arbitrary resampler's access pattern, resamp.rs:141-154 with the
+// phase schedule precomputed): y[n] = scale * sum_k hb[idx[n]][k] * X[n-k].
+// One lane per output; samples from an LDS tile, taps gathered from L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelTile = 1024;
+
+template <class K>
+__global__ void __launch_bounds__(256)
+firpfb_select_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                     const typename K::C *__restrict__ hb, const uint32_t *__restrict__ idx,
+                     int nf, int Ls, typename K::C scale, typename K::T *__restrict__ y, size_t n) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    const size_t n0 = (size_t)blockIdx.x * kSelTile;
+    const int nt = (int)((n - n0) < (size_t)kSelTile ? (n - n0) : (size_t)kSelTile);
+    const long long base = (long long)n0 - (Ls - 1);
+    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    __syncthreads();
+    for (int nl = threadIdx.x; nl < nt; nl += 256) {
+        uint32_t b = idx[n0 + nl];
+        if (b >= (uint32_t)nf) b = (uint32_t)nf - 1;     // host validates; clamp keeps the read in range
+        const C *hrow = hb + (size_t)b * Ls;
+        T acc = zero_of<T>();
+        for (int k = 0; k < Ls; ++k) acc = mac(acc, xs[nl + (Ls - 1) - k], hrow[k]);
+        y[n0 + nl] = mul(acc, scale);
+    }
+}
+
+template <class K>
+int launch_firpfb_select(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
+                         const uint32_t *idx, int nf, int Ls, typename K::C scale,
+                         typename K::T *y, size_t n, hipStream_t st) {
+    using T = typename K::T;
+    if (n == 0) return YAGI_OK;
+    const size_t xs_bytes = (size_t)(kSelTile + Ls - 1) * sizeof(T);
+    if (xs_bytes > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "branch filters too long (%d taps)", Ls);
+    const size_t nblk = (n + kSelTile - 1) / kSelTile;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    firpfb_select_kernel<K><<<(unsigned)nblk, 256, xs_bytes, st>>>(win, x, hb, idx, nf, Ls, scale, y, n);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+template int launch_firpfb_select<RRRF>(const float *, const float *, const float *, const uint32_t *, int, int, float, float *, size_t, hipStream_t);
+template int launch_firpfb_select<CRCF>(const cf32 *, const cf32 *, const float *, const uint32_t *, int, int, float, cf32 *, size_t, hipStream_t);
+template int launch_firpfb_select<CCCF>(const cf32 *, const cf32 *, const cf32 *, const uint32_t *, int, int, cf32, cf32 *, size_t, hipStream_t);
+
+}  // namespace yagi

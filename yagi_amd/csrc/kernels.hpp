@@ -1,0 +1,80 @@
+// kernels.hpp -- launcher declarations shared by the kernel translation units and capi.hip.
+// Every launcher is asynchronous on `st`, performs no allocation and no host synchronisation
+// (so a caller may capture it into a hipGraph), and returns a yagi_status.
+#pragma once
+#include "common.hpp"
+
+namespace yagi {
+
+// Type combinations of the FIR family (T = sample/output type, C = coefficient type).
+struct RRRF { using T = float; using C = float; static constexpr int id = 0; };
+struct CRCF { using T = cf32;  using C = float; static constexpr int id = 1; };
+struct CCCF { using T = cf32;  using C = cf32;  static constexpr int id = 2; };
+
+// ---- misc_kernels.hip ----------------------------------------------------------------------
+int launch_gen_real(uint64_t seed, uint64_t first, size_t n, float *x, hipStream_t st);
+int launch_gen_complex(uint64_t seed, uint64_t first, size_t n, cf32 *x, hipStream_t st);
+
+// y[0] = post * sum_i a[i] * b[rev ? n-1-i : i]; `partials` needs dotprod_num_partials(n)
+// elements of the output type.  Fixed-order two-pass combine => bitwise reproducible.
+size_t dotprod_num_partials(size_t n);
+template <class A, class B, class O, class S>
+int launch_dotprod(const A *a, const B *b, size_t n, bool rev_b, S post, O *partials, O *y,
+                   hipStream_t st);
+
+// new_win = last L samples of (old_win ++ x[0..n))
+template <class T>
+int launch_update_window(const T *old_win, const T *x, size_t n, int L, T *new_win, hipStream_t st);
+
+// ---- fir_kernels.hip -----------------------------------------------------------------------
+// y[i] = scale * sum_{k<L} h[k] * X[i*M - k],  X = win(L samples, oldest first) ++ x,
+// X index 0 = x[0].  i in [0, ny).  taps in natural order h[0..L).
+template <class K>
+int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
+                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st);
+
+// polyphase bank, all branches per input sample: y[n*nf + i] = scale * sum_k hb[i][k] X[n-k]
+// branch taps hb laid out [nf][Ls] in natural (newest-first) order.
+template <class K>
+int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
+                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st);
+// branch chosen per sample: y[n] = scale * sum_k hb[idx[n]][k] X[n-k]
+template <class K>
+int launch_firpfb_select(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
+                         const uint32_t *idx, int nf, int Ls, typename K::C scale,
+                         typename K::T *y, size_t n, hipStream_t st);
+
+// ---- stream_kernels.hip (crcf M=1 hot case; headline fused FIR -> 4096-pt FFT) -----------------
+// taps_pad = h zero-padded to Lp = roundup(L, 32) floats.
+constexpr int kSlideMaxTaps = 1024;
+int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad, int L, int Lp,
+                          float scale, cf32 *y, size_t ny, hipStream_t st);
+int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pad, const float *apack,
+                            int L, int Lp, float scale, const cf32 *tw4096, cf32 *spectra,
+                            size_t nframes, int variant, hipStream_t st);
+
+// ---- fft_kernels.hip -----------------------------------------------------------------------
+struct FftPlanDev {
+    int n = 0;
+    int dir = 0;
+    int nfac = 0;
+    int fac[16] = {0};
+    const cf32 *tw = nullptr;        // W_n^m, m in [0,n), sign per direction
+};
+constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
+int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st);
+int launch_fft_shift(cf32 *buf, size_t n, size_t batch, hipStream_t st);
+
+// ---- chan_kernels.hip ----------------------------------------------------------------------
+// firpfbch analyzer: hist = the (p-1)*M samples preceding x[0] (oldest first).
+int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
+                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st);
+// firpfbch2 analyzer: hist = the 2*m*M - M/2 ... samples preceding x[0]; step0 = index of the
+// first step (parity selects the half rotation).  rank/nranks select sub-bands k = rank + nranks*q.
+int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
+                     const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
+                     hipStream_t st);
+int launch_firpfbch2_assemble(const cf32 *gathered, size_t nsteps, int M, int nranks, cf32 *y,
+                              hipStream_t st);
+
+}  // namespace yagi
