@@ -41,21 +41,22 @@ FP32_PEAK_TFLOPS = 157.3
 
 
 def cpu_baseline(h, scale, budget_s=12.0):
-    """time the oracle (single thread, C -O2 no fast-math) on a bounded sample of the same stream"""
-    import numpy as np
-
+    """time the oracle (single thread, C -O2, no fast-math) on a bounded sample of the same stream:
+    1024-frame chunks of the C2 stream until ~budget_s of CPU work has been done"""
     from oracle import oracle
-    x = oracle.gen_complex(SEED, 64 * NFFT)
-    t0 = time.perf_counter()
-    oracle.stream_fir_fft(h, scale, x[: 4 * NFFT], NFFT)
-    probe = (time.perf_counter() - t0) / 4
-    frames = int(max(8, min(64, budget_s / max(probe, 1e-6))))
-    t0 = time.perf_counter()
-    oracle.stream_fir_fft(h, scale, x[: frames * NFFT], NFFT)
-    dt = time.perf_counter() - t0
+    chunk_frames = 1024
+    x = oracle.gen_complex(SEED, chunk_frames * NFFT)
+    oracle.stream_fir_fft(h, scale, x[: 8 * NFFT], NFFT)          # warm caches / page in
+    frames, dt = 0, 0.0
+    while dt < budget_s and frames < 64 * chunk_frames:
+        t0 = time.perf_counter()
+        oracle.stream_fir_fft(h, scale, x, NFFT)
+        dt += time.perf_counter() - t0
+        frames += chunk_frames
     return {"value": round(frames * NFFT / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} frames x {NFFT} samples of the same stream (oracle/yagi_oracle.c "
-                      f"yo_stream_fir_fft: sequential-sum firfilt_crcf + f32 radix-4 FFT), {dt:.1f} s",
+            "sample": f"{frames} frames x {NFFT} samples ({frames * NFFT / 1e6:.0f} Msamples) of the same stream in "
+                      f"{chunk_frames}-frame chunks, {dt:.1f} s; oracle/yagi_oracle.c yo_stream_fir_fft = "
+                      "sequential-sum firfilt_crcf (firfilt.rs:267-278) + f32 radix-4 FFT, gcc -O2 no fast-math",
             "host_cores_available": os.cpu_count()}
 
 

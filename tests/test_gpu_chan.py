@@ -46,7 +46,7 @@ def test_firpfbch_kaiser_ctor_and_tone(ya, oracle):
 
 def test_firpfbch_equals_firdecim_per_channel(ya, oracle):
     """channel k of the analyzer == mix down by k/M, lowpass with the prototype, keep 1 of M
-    (up to the polyphase phase convention: y_k[f] uses input up to sample f*M + M-1)."""
+    sampled at n = f*M + M-1:  y_k[f] = sum_s h[fM+M-1-s] x[s] e^{-j 2 pi k s / M}."""
     M, m = 8, 3
     h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)[: 2 * M * m]
     nfr = 64
@@ -56,7 +56,7 @@ def test_firpfbch_equals_firdecim_per_channel(ya, oracle):
     for k in range(M):
         mixed = x.astype(np.complex128) * np.exp(-2j * np.pi * k * n / M)
         full = np.convolve(mixed, h.astype(np.float64))[: nfr * M]
-        want = full[M - 1:: M] * np.exp(2j * np.pi * k * (M - 1) / M)      # newest sample = f*M + M-1
+        want = full[M - 1:: M]                  # newest sample of frame f is f*M + M-1
         assert rel_l2(got[:, k], want) <= 1e-5, k
 
 

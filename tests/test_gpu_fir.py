@@ -33,7 +33,7 @@ def test_firfilt_golden(ya, kind, case):
         a, b = q1.execute(), q2.execute_one(xi)
         assert abs(a - yi) <= 1e-3 * abs(yi) + 1e-6 and abs(b - yi) <= 1e-3 * abs(yi) + 1e-6
     if kind == "crcf":
-        for choice in (1, 2):                       # both block kernels
+        for choice in (1, 2, 3):                    # general / sliding / MFMA Toeplitz kernels
             q = ya.FirFilter(kind, h)
             q.set_kernel(choice)
             np.testing.assert_allclose(q.execute_block(x), y, rtol=1e-3, atol=1e-6)
@@ -123,12 +123,26 @@ def test_firfilt_integer_inputs_bit_exact(ya, oracle, kind):
         want = oracle.FirFilter(kind, h).execute_block(x)
         assert np.array_equal(ya.FirFilter(kind, h).execute_block(x), want)
         if kind == "crcf":
-            for choice in (1, 2):
+            for choice in (1, 2, 3):
                 q = ya.FirFilter(kind, h)
                 q.set_kernel(choice)
                 a = q.execute_block(x[: n // 2])
                 b = q.execute_block(x[n // 2:])
                 assert np.array_equal(np.concatenate([a, b]), want)
+
+
+@pytest.mark.parametrize("L", [1, 3, 16, 63, 64, 65, 100, 128, 129, 200, 255, 256])
+def test_firfilt_crcf_mfma_kernel_lengths(ya, oracle, L):
+    """MFMA Toeplitz form (kernel 3) across the padded-length classes 64/128/256 and ragged blocks"""
+    rng = np.random.default_rng(1000 + L)
+    h, x = rand_taps(rng, "crcf", L), rand_samples(rng, "crcf", 3 * 4096 + 777)
+    q = ya.FirFilter("crcf", h)
+    q.set_kernel(3)
+    q.set_scale(-1.5)
+    got = np.concatenate([q.execute_block(x[:5000]), q.execute_block(x[5000:5001]), q.execute_block(x[5001:])])
+    truth = oracle.fir_block_f64("crcf", h, x, scale=-1.5)
+    assert np.max(np.abs(got - truth)) <= fir_bound("crcf", h, x) * 1.5
+    assert rel_l2(got, truth) <= 2e-6
 
 
 def test_config_c1_firfilt_rrrf_63tap_1M(ya, oracle):
@@ -155,7 +169,7 @@ def test_config_c2_firfilt_crcf_256tap_stream(ya, oracle):
     n = 1 << 20
     x = oracle.gen_complex(SEED + 2, n)
     truth = oracle.fir_block_f64("crcf", h, x, scale=0.4)
-    for choice in (0, 1, 2):
+    for choice in (0, 1, 2, 3):
         q = ya.FirFilter("crcf", h)
         q.set_scale(0.4)
         q.set_kernel(choice)

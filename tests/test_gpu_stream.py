@@ -25,12 +25,14 @@ def test_stream_small_vs_oracle(ya, oracle, L):
     rng = np.random.default_rng(L)
     h = (rng.standard_normal(L) / np.sqrt(L)).astype(np.float32)
     x = oracle.gen_complex(SEED + 2, 12 * 4096)
-    q = ya.FirFftStream(h)
-    q.set_scale(0.4)
-    got = np.concatenate([q.execute(x[: 5 * 4096]), q.execute(x[5 * 4096:])])     # state carried across calls
     truth = spectra_truth(oracle, h, 0.4, x)
-    for f in range(12):
-        assert rel_l2(got[f], truth[f]) <= 1e-5, f
+    for variant in ((1, 2) if L <= 256 else (1,)):          # 1 = sliding VALU FIR, 2 = MFMA Toeplitz FIR
+        q = ya.FirFftStream(h)
+        q.set_scale(0.4)
+        q.set_variant(variant)
+        got = np.concatenate([q.execute(x[: 5 * 4096]), q.execute(x[5 * 4096:])])     # state carried across calls
+        for f in range(12):
+            assert rel_l2(got[f], truth[f]) <= 1e-5, (variant, f)
     # same result as the unfused objects (FirFilter then Fft), to f32 rounding
     fir = ya.FirFilter("crcf", h)
     fir.set_scale(0.4)
@@ -61,14 +63,16 @@ def test_stream_integer_alignment_exact(ya):
     h = np.ones(256, np.float32)
     x = np.zeros(3 * 4096, np.complex64)
     x[4096 - 100] = 1.0          # its 256-sample response straddles the frame 0 / frame 1 boundary
-    q = ya.FirFftStream(h)
-    got = q.execute(x)
     y = np.zeros(3 * 4096)
     y[4096 - 100: 4096 - 100 + 256] = 1.0
-    for f in range(3):
-        truth = np.fft.fft(y[f * 4096:(f + 1) * 4096])
-        assert np.max(np.abs(got[f] - truth)) <= 2e-3
-    assert np.max(np.abs(got[2])) == 0.0
+    for variant in (1, 2):
+        q = ya.FirFftStream(h)
+        q.set_variant(variant)
+        got = q.execute(x)
+        for f in range(3):
+            truth = np.fft.fft(y[f * 4096:(f + 1) * 4096])
+            assert np.max(np.abs(got[f] - truth)) <= 2e-3
+        assert np.max(np.abs(got[2])) == 0.0
 
 
 def test_headline_config_full_block(ya, oracle):
@@ -81,8 +85,16 @@ def test_headline_config_full_block(ya, oracle):
     dy = ya.DeviceArray(n, np.complex64)
     q = ya.FirFftStream(h)
     q.set_scale(0.4)
+    q2 = ya.FirFftStream(h)                 # the other FIR form must give the same spectra
+    q2.set_scale(0.4)
+    q2.set_variant(2)
+    dy_alt = ya.DeviceArray(n, np.complex64)
+    q2.execute_dev(dx, nframes, dy_alt)
     q.execute_dev(dx, nframes, dy)
     ya.synchronize()
+    for f in (5, 3000):
+        assert rel_l2(dy_alt.to_numpy(4096, offset=f * 4096), dy.to_numpy(4096, offset=f * 4096)) <= 2e-6
+    dy_alt.free()
     for f in (0, 1, 2047, 4095):
         lo = max(0, f * 4096 - 255)
         xs = dx.to_numpy((f + 1) * 4096 - lo, offset=lo)

@@ -12,7 +12,9 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libyagi_hip.so"
+# YAGI_HIP_LIB lets the kernel-tuning scripts under tools/ load an alternative build of the SAME
+# library (different compile flags); it is never a different back-end.
+LIB_PATH = Path(os.environ.get("YAGI_HIP_LIB") or (_HERE / "libyagi_hip.so"))
 
 
 class cf32(C.Structure):

@@ -135,9 +135,11 @@ struct FirFilt {
     C scale = one_of<C>();
     DevBuf taps;               // h[0..L) on device
     DevBuf taps_pad;           // crcf only: zero-padded to Lp floats for the sliding kernel
+    DevBuf apack;              // crcf only, L <= 256: Toeplitz A-operand table of the MFMA kernel
+    int Lm = 0;                // padded length of the MFMA form (0 = not available)
     DevWindow<T> w;
     Workspace ws;
-    int kernel_choice = 0;     // 0 auto, 1 general, 2 sliding (crcf)
+    int kernel_choice = 0;     // 0 auto, 1 general, 2 sliding (crcf), 3 MFMA Toeplitz (crcf, L <= 256)
 
     int load_taps(const C *hh, size_t n) {
         if (n == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
@@ -152,6 +154,13 @@ struct FirFilt {
             std::memcpy(hp.data(), h.data(), n * sizeof(float));
             YG_TRY(taps_pad.alloc((size_t)Lp * sizeof(float)));
             YG_TRY(upload(taps_pad.p, hp.data(), (size_t)Lp * sizeof(float), st));
+            Lm = mfma_lp_for(L);
+            if (Lm) {
+                std::vector<float> ap(toeplitz_pack_floats(Lm));
+                pack_toeplitz_taps(reinterpret_cast<const float *>(h.data()), L, Lm, ap.data());
+                YG_TRY(apack.alloc(ap.size() * sizeof(float)));
+                YG_TRY(upload(apack.p, ap.data(), ap.size() * sizeof(float), st));
+            }
         }
         return YAGI_OK;
     }
@@ -173,7 +182,9 @@ template <>
 int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
     YG_TRY(w.flush(st));
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
-    if (slide && Lp <= kSlideMaxTaps)
+    if (kernel_choice == 3 && Lm)
+        YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st));
+    else if (slide && Lp <= kSlideMaxTaps)
         YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st));
     else
         YG_TRY((launch_fir_block<CRCF>(w.dev(), x, taps.as<float>(), L, 1, scale, y, n, st)));
@@ -811,7 +822,7 @@ YAGI_FIR_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
 // crcf-only knob: which block kernel execute_block uses (0 auto, 1 general, 2 sliding)
 extern "C" int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice) {
     CHECK_Q(q);
-    if (choice < 0 || choice > 2) return fail(YAGI_ERR_CONFIG, "unknown kernel choice %d", choice);
+    if (choice < 0 || choice > 3) return fail(YAGI_ERR_CONFIG, "unknown kernel choice %d", choice);
     q->kernel_choice = choice;
     return YAGI_OK;
 }
@@ -917,6 +928,7 @@ int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->f
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     CHECK_Q(q);
     if (variant < 0 || variant > 2) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
     q->variant = variant;
     return YAGI_OK;
 }
@@ -927,7 +939,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_PTR(spectra);
     auto &f = q->fir;
     YG_TRY(f.w.flush(f.st));
-    YG_TRY(launch_firfft_crcf_4096(f.w.dev(), x, f.taps_pad.as<float>(), nullptr, f.L, f.Lp, f.scale,
+    YG_TRY(launch_firfft_crcf_4096(f.w.dev(), x, f.taps_pad.as<float>(), f.apack.as<float>(), f.L, f.Lp, f.Lm, f.scale,
                                    q->tw.as<cf32>(), spectra, nframes, q->variant, f.st));
     return f.w.advance(x, nframes * q->nfft, f.st);
 }

@@ -50,8 +50,15 @@ constexpr int kSlideMaxTaps = 1024;
 int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad, int L, int Lp,
                           float scale, cf32 *y, size_t ny, hipStream_t st);
 int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pad, const float *apack,
-                            int L, int Lp, float scale, const cf32 *tw4096, cf32 *spectra,
+                            int L, int Lp, int Lm, float scale, const cf32 *tw4096, cf32 *spectra,
                             size_t nframes, int variant, hipStream_t st);
+// MFMA Toeplitz form (L <= 256): Lm = mfma_lp_for(L) in {64,128,256} (0 = unsupported);
+// apack = pack_toeplitz_taps(h, L, Lm), toeplitz_pack_floats(Lm) floats.
+int mfma_lp_for(int L);
+size_t toeplitz_pack_floats(int Lp);
+void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack_host);
+int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lm, float scale,
+                         cf32 *y, size_t ny, hipStream_t st);
 
 // ---- fft_kernels.hip -----------------------------------------------------------------------
 struct FftPlanDev {

@@ -48,10 +48,39 @@ __device__ __forceinline__ void load_row(float2 (&w)[16], const float2 *__restri
 }
 
 // Stage X[base .. base + nspan) into the padded LDS image; X index < -L reads as zero (only the
-// zero-padded taps ever meet it).
+// zero-padded taps ever meet it).  nspan = kTile + Lp (even), base = tile0 - (Lp - 1) (odd).
+// Fast path (tile fully inside x, x 16-B aligned): every lane issues ALL its 16-byte loads first
+// (9 x global_load_dwordx4 in flight per lane, 1 KiB contiguous per wave instruction), then writes
+// LDS -- one HBM round trip per tile instead of one per element.
 __device__ __forceinline__ void stage_span(float2 *__restrict__ xs, const float2 *__restrict__ win,
                                            const float2 *__restrict__ x, long long base, int nspan,
                                            int L, long long x_len) {
+    const long long first = base - 1;                 // even X index: pairs (first + 2q, first + 2q + 1)
+    const bool fast = first >= 0 && first + nspan + 2 <= x_len &&
+                      ((reinterpret_cast<unsigned long long>(x) & 15ull) == 0);
+    if (fast) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + first);
+        const int npairs = (nspan + 2) >> 1;          // covers span indices -1 .. nspan
+        // batches of 5 loads in flight per lane (bounded register footprint: 20 VGPRs)
+        for (int q0 = threadIdx.x; q0 < npairs; q0 += 5 * 256) {
+            float4 r[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = q0 + 256 * i;
+                r[i] = src[q < npairs ? q : npairs - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = q0 + 256 * i;
+                const int u = 2 * q - 1;              // span index of r.xy ; r.zw is u + 1
+                if (q < npairs) {
+                    if (u >= 0) xs[padded(u)] = make_float2(r[i].x, r[i].y);
+                    if (u + 1 < nspan) xs[padded(u + 1)] = make_float2(r[i].z, r[i].w);
+                }
+            }
+        }
+        return;
+    }
     for (int u = threadIdx.x; u < nspan; u += 256) {
         const long long idx = base + u;
         float2 v = make_float2(0.f, 0.f);
@@ -85,15 +114,15 @@ firfilt_crcf_slide_kernel(const float2 *__restrict__ win, const float2 *__restri
                           float2 *__restrict__ y, size_t ny) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
-    const int nrows = (kTile + Lp) >> 4;
-    float2 *ys = xs + nrows * kRowPad;       // 4096 outputs, padded rows
+    float2 *ys = xs;                         // 4096 outputs, padded rows: reuses the span image once the FIR loop is done
     for (size_t tile = blockIdx.x; tile * kTile < ny; tile += gridDim.x) {
         const size_t o0 = tile * kTile;
         const long long base = (long long)o0 - (Lp - 1);
-        stage_span(xs, win, x, base, kTile + Lp - 1, L, (long long)ny);
+        stage_span(xs, win, x, base, kTile + Lp, L, (long long)ny);
         __syncthreads();
         float2 acc[16];
         fir_tile_slide(acc, xs, taps_pad, Lp);
+        __syncthreads();                     // every lane is done reading the span
 #pragma unroll
         for (int j = 0; j < 16; ++j)
             ys[threadIdx.x * kRowPad + j] = make_float2(acc[j].x * scale, acc[j].y * scale);
@@ -105,22 +134,25 @@ firfilt_crcf_slide_kernel(const float2 *__restrict__ win, const float2 *__restri
 }
 
 // ---- fused FIR -> 4096-point forward FFT (the headline) -----------------------------------------
-__global__ void __launch_bounds__(256)
+#ifndef YG_FUSED_WAVES
+#define YG_FUSED_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, YG_FUSED_WAVES)
 firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                               const float *__restrict__ taps_pad, int L, int Lp, float scale,
                               const float2 *__restrict__ tw, float2 *__restrict__ spectra,
                               size_t nframes) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
-    const int nrows = (kTile + Lp) >> 4;
-    float2 *fl = xs + nrows * kRowPad;       // kFft4096LdsFloat2: FIR-output image, then FFT exchanges
+    float2 *fl = xs;                         // FIR-output image, then the FFT exchanges: reuses the span image
     const long long x_len = (long long)nframes * kTile;
     for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
         const long long base = (long long)f * kTile - (Lp - 1);
-        stage_span(xs, win, x, base, kTile + Lp - 1, L, x_len);
+        stage_span(xs, win, x, base, kTile + Lp, L, x_len);
         __syncthreads();
         float2 v[16];
         fir_tile_slide(v, xs, taps_pad, Lp);
+        __syncthreads();                     // every lane is done reading the span
         // lane t holds outputs 16t+j; FFT pass 1 wants lane b to hold outputs 256a+b
 #pragma unroll
         for (int j = 0; j < 16; ++j)
@@ -134,8 +166,9 @@ firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__re
 }
 
 static size_t slide_lds_bytes(int Lp) {
-    const int nrows = (kTile + Lp) >> 4;
-    return ((size_t)nrows * kRowPad + kFft4096LdsFloat2) * sizeof(float2);
+    const int nrows = (kTile + Lp) >> 4;     // span image; the 4352-float2 output/FFT image aliases it
+    const size_t span = (size_t)nrows * kRowPad;
+    return (span > (size_t)kFft4096LdsFloat2 ? span : (size_t)kFft4096LdsFloat2) * sizeof(float2);
 }
 
 static int raise_lds_limit(const void *fn, bool &done) {
@@ -144,6 +177,150 @@ static int raise_lds_limit(const void *fn, bool &done) {
         done = true;
     }
     return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA form of the same FIR: the batched filter re-cast as a dense tap x sample product.
+//   D[m][n] += sum_u T[m][u] * X[u][n]      (v_mfma_f32_16x16x4_f32: exact f32 FMA chain)
+//   m  = 16 consecutive output times (one row tile), n = 8 stream segments x {re, im},
+//   T  = Toeplitz tap matrix T[m][u] = h[m - u + Lp - 1] (zero outside [0, L)),
+//   X  = sample windows X[u][(seg,c)] = x[T0 + 64*seg - (Lp-1) + u].c
+// A task = 512 consecutive outputs = 8 segments of 64 = 4 row tiles.  Shifting a row tile by 16
+// outputs shifts its window by 16 samples = 4 K-steps, so ONE set of NS = ceil((Lp+15)/4) A
+// registers (loaded once per kernel from the host-packed table `apack`) serves all four row tiles
+// and every B register (one ds_read_b32 from the staged span) feeds up to 4 MFMAs.
+// Overhead vs the minimum flop count: (Lp+15)/Lp (6 % at 256 taps).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NS>
+__device__ __forceinline__ void load_apack(float (&a)[NS], const float *__restrict__ apack) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = apack[s * 64 + lane];
+}
+
+// acc[tt][r] = sum_k h[k] X[T0 + 64*seg + 16*tt + 4*(lane>>4) + r - k].c   (seg = (lane&15)>>1, c = lane&1)
+template <int NS>
+__device__ __forceinline__ void fir_task_mfma(f32x4 (&acc)[4], const float (&a)[NS],
+                                              const float *__restrict__ xsf, int T0) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15, seg = j >> 1, c = j & 1;
+    // span index i = T0 + 64*seg + 4*sp + k ; padded(i) = i + (T0>>4) + 4*seg + (sp>>2)
+    const float *p = xsf + 2 * (T0 + 64 * seg + k + (T0 >> 4) + 4 * seg) + c;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B operands are prefetched PF steps ahead (static ring in registers) so the MFMA stream never
+    // waits on an LDS round trip; the compiler turns the waits into counted lgkmcnt(N).
+    constexpr int PF = 8;
+    float bq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) bq[i] = p[2 * (4 * i + (i >> 2))];
+#pragma unroll
+    for (int sp = 0; sp < NS + 12; ++sp) {
+        const float b = bq[sp % PF];
+        if (sp + PF < NS + 12) bq[sp % PF] = p[2 * (4 * (sp + PF) + ((sp + PF) >> 2))];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int s = sp - 4 * tt;
+            if (s >= 0 && s < NS) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b, acc[tt], 0, 0, 0);
+        }
+    }
+}
+
+// scatter a task's accumulators into the padded output image (float view)
+__device__ __forceinline__ void store_task_mfma(const f32x4 (&acc)[4], float *__restrict__ outf, int T0,
+                                                float scale) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15, seg = j >> 1, c = j & 1;
+    // o = T0 + 64*seg + 16*tt + 4*k + r ; padded(o) = o + (T0>>4) + 4*seg + tt
+    float *p = outf + 2 * (T0 + 64 * seg + 4 * k + (T0 >> 4) + 4 * seg) + c;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[2 * (16 * tt + r + tt)] = acc[tt][r] * scale;
+}
+
+template <int NS, bool FUSED>
+__global__ void __launch_bounds__(256)
+fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
+                     const float *__restrict__ apack, int L, int Lp, float scale,
+                     const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *xs = reinterpret_cast<float2 *>(smem);
+    float a[NS];
+    load_apack<NS>(a, apack);
+    const int wave = threadIdx.x >> 6;
+    // FUSED: n_units = frames (tile == frame); else n_units = output samples
+    const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
+    const long long x_len = FUSED ? (long long)n_units * kTile : (long long)n_units;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t o0 = tile * kTile;
+        stage_span(xs, win, x, (long long)o0 - (Lp - 1), kTile + Lp, L, x_len);
+        __syncthreads();
+        f32x4 acc0[4], acc1[4];
+        fir_task_mfma<NS>(acc0, a, reinterpret_cast<const float *>(xs), 512 * wave);
+        fir_task_mfma<NS>(acc1, a, reinterpret_cast<const float *>(xs), 512 * (wave + 4));
+        __syncthreads();                         // all waves done reading the span: reuse it as output image
+        store_task_mfma(acc0, reinterpret_cast<float *>(xs), 512 * wave, scale);
+        store_task_mfma(acc1, reinterpret_cast<float *>(xs), 512 * (wave + 4), scale);
+        __syncthreads();
+        if (FUSED) {
+            float2 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
+            __syncthreads();
+            fft4096_passes<-1>(v, xs, tw, out + o0);
+        } else {
+            const int nt = (int)((n_units - o0) < (size_t)kTile ? (n_units - o0) : (size_t)kTile);
+            for (int o = threadIdx.x; o < nt; o += 256) out[o0 + o] = xs[padded(o)];
+            __syncthreads();
+        }
+    }
+}
+
+// host: A-operand table.  apack[s*64 + lane] = T[m = lane&15][u = 4s + (lane>>4)] = h[m - u + Lp - 1]
+int mfma_lp_for(int L) { return L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 256 ? 256 : 0)); }
+size_t toeplitz_pack_floats(int Lp) { return (size_t)((Lp + 15 + 3) / 4) * 64; }
+void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack) {
+    const int NS = (Lp + 15 + 3) / 4;
+    for (int s = 0; s < NS; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, u = 4 * s + (lane >> 4);
+            const int k = m - u + Lp - 1;
+            apack[s * 64 + lane] = (k >= 0 && k < L) ? h[k] : 0.0f;
+        }
+}
+
+template <int NS, bool FUSED>
+static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
+                         const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
+    static bool raised = false;
+    YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED>), raised));
+    const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)(ntiles < 65536 ? ntiles : 65536);
+    fir_crcf_mfma_kernel<NS, FUSED><<<grid, 256, slide_lds_bytes(Lp), st>>>(
+        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, Lp, scale,
+        reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+template <bool FUSED>
+static int launch_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
+                       const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
+    switch (Lp) {
+        case 64: return launch_mfma_t<20, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 128: return launch_mfma_t<36, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 256: return launch_mfma_t<68, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+    }
+    return fail(YAGI_ERR_INTERNAL, "mfma FIR: unsupported padded length %d", Lp);
+}
+
+int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
+                         cf32 *y, size_t ny, hipStream_t st) {
+    if (ny == 0) return YAGI_OK;
+    return launch_mfma<false>(win, x, apack, L, Lp, scale, nullptr, y, ny, st);
 }
 
 // M = 1 crcf block FIR with the sliding kernel; taps_pad = h zero-padded to Lp = roundup(L, 32)
@@ -163,12 +340,14 @@ int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad,
 }
 
 int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pad, const float *apack,
-                            int L, int Lp, float scale, const cf32 *tw4096, cf32 *spectra,
+                            int L, int Lp, int Lm, float scale, const cf32 *tw4096, cf32 *spectra,
                             size_t nframes, int variant, hipStream_t st) {
-    (void)apack;
-    (void)variant;
     if (nframes == 0) return YAGI_OK;
     if (Lp > kSlideMaxTaps || (Lp & 31)) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%d taps)", L);
+    if (variant == 2) {          // MFMA Toeplitz FIR
+        if (!Lm || !apack) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps (got %d)", L);
+        return launch_mfma<true>(win, x, apack, L, Lm, scale, tw4096, spectra, nframes, st);
+    }
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(firfft_crcf_4096_slide_kernel), raised));
     const unsigned grid = (unsigned)(nframes < 65536 ? nframes : 65536);
