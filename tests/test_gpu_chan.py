@@ -134,3 +134,30 @@ def test_chan_config(ya):
     d = ya.DeviceArray(64, np.complex64)
     with pytest.raises(ya.ConfigError):
         q.analyzer_execute_shard_dev(d, 4, 0, 3, d)        # 8 channels do not shard 3 ways
+
+
+def test_firpfbch2_sharded_driver_rccl_world1(ya, oracle):
+    """yagi_amd.dist.firpfbch2_analyze_sharded end to end over RCCL (backend nccl) with the one GPU
+    this box has: world_size 1 exercises shard kernel -> all_gather_into_tensor -> assemble kernel."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from yagi_amd import dist as yd
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        M, m, ns = 256, 4, 64
+        q = ya.FirPfbCh2.new_kaiser(M, m, 60.0)
+        x = oracle.gen_complex(SEED + 5, ns * (M // 2))
+        xt = torch.from_numpy(x).cuda()
+        y = yd.firpfbch2_analyze_sharded(q, xt, ns)
+        torch.cuda.synchronize()
+        want = ya.FirPfbCh2.new_kaiser(M, m, 60.0).analyzer_execute(x)
+        assert rel_l2(y.cpu().numpy(), want) <= 1e-6
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""profiling target: launch each selected kernel a few times (for rocprofv3 --pmc / --kernel-trace).
+usage: python3 tools/prof_target.py [fused fused2 fir2 fir3 fft fft_big chan1 chan2] """
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+import yagi_amd as ya
+
+what = sys.argv[1:] or ["fused"]
+n = 1 << 24
+dev = torch.device("cuda")
+x = torch.empty(n, dtype=torch.complex64, device=dev)
+y = torch.empty(2 * n, dtype=torch.complex64, device=dev)
+st = torch.cuda.current_stream()
+ya.gen_complex_dev(0x59414749 + 2, n, out=x, stream=st.cuda_stream)
+h = ya.fir_design_kaiser(256, 0.2, 60.0)
+keep = []
+for w in what:
+    if w in ("fused", "fused2"):
+        f = ya.FirFftStream(h); f.set_stream(st.cuda_stream); f.set_variant(1 if w == "fused" else 2)
+        fn = lambda f=f: f.execute_dev(x, n // 4096, y)
+    elif w in ("fir1", "fir2", "fir3"):
+        q = ya.FirFilter("crcf", h); q.set_kernel(int(w[3])); q.set_stream(st.cuda_stream)
+        fn = lambda q=q: q.execute_block_dev(x, n, y)
+    elif w == "fft":
+        p = ya.Fft(4096, ya.Direction.Forward)
+        fn = lambda p=p: p.run_batch_dev(x, y, n // 4096, st.cuda_stream)
+    elif w == "chan1":
+        c = ya.FirPfbCh.new_kaiser(64, 8, 60.0); c.set_stream(st.cuda_stream)
+        fn = lambda c=c: c.analyzer_execute_dev(x, n // 64, y)
+    elif w == "chan2":
+        c = ya.FirPfbCh2.new_kaiser(256, 4, 60.0); c.set_stream(st.cuda_stream)
+        fn = lambda c=c: c.analyzer_execute_dev(x, n // 128, y)
+    else:
+        raise SystemExit(f"unknown target {w}")
+    keep.append(fn)
+    for _ in range(4):
+        fn()
+torch.cuda.synchronize()

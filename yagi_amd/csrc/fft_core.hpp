@@ -64,19 +64,19 @@ template <int SIGN>
 __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restrict__ lds,
                                                const float2 *__restrict__ tw,
                                                float2 *__restrict__ out) {
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     // ---- pass 1 (lane b = t) ----
     dft16<SIGN>(v);
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         float2 z = v[dft16_pos(c)];
-        if (c) z = cmul(z, tw[t * c]);
+        if (c) z = cmul(z, tw[(unsigned)(t * c)]);
         lds[c * kEx1Stride + t] = z;
     }
     __syncthreads();
     // ---- pass 2 (lane = c*16 + b') ----
     {
-        const int c = t >> 4, bp = t & 15;
+        const unsigned c = t >> 4, bp = t & 15;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = lds[c * kEx1Stride + 16 * a + bp];
         __syncthreads();                       // exchange-1 reads done before the buffer is reused
@@ -84,7 +84,7 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
 #pragma unroll
         for (int cp = 0; cp < 16; ++cp) {
             float2 u = v[dft16_pos(cp)];
-            if (cp) u = cmul(u, tw[16 * bp * cp]);
+            if (cp) u = cmul(u, tw[(unsigned)(16 * bp * cp)]);
             lds[bp * kEx2Stride + cp * 16 + c] = u;
         }
     }
