@@ -21,7 +21,7 @@
 // One workgroup owns a tile of frames: input tile + history staged in LDS once (8 B/sample from
 // HBM), branch dot products from LDS, the M-point DFTs as Stockham passes in LDS, coalesced
 // [frame][channel] stores (8 or 16 B per input sample).  HBM-bound by construction.
-#include "devmath.hpp"
+#include "fft_radix.hpp"
 #include "kernels.hpp"
 
 namespace yagi {
@@ -82,37 +82,54 @@ __device__ __forceinline__ float2 load_hist(const float2 *__restrict__ hist, int
 // ---------------------------------------------------------------------------------------------
 // firpfbch analyzer
 // ---------------------------------------------------------------------------------------------
+// POW2: M is a power of two -> register-butterfly Stockham passes (fft_radix.hpp); otherwise the
+// general one-output-per-lane passes.  Taps (transposed, [n][c]) and the W_M table live in LDS.
+template <bool POW2>
 __global__ void __launch_bounds__(256)
 firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                 const float *__restrict__ h, int M, int p, const float2 *__restrict__ twM,
-                FacList fl, float2 *__restrict__ y, size_t nframes, int F) {
+                FacList fl, Pow2Plan plan, float2 *__restrict__ y, size_t nframes, int F) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);              // (F + p - 1) * M samples
     float2 *va = xs + (size_t)(F + p - 1) * M;                  // F * M
     float2 *vb = va + (size_t)F * M;                            // F * M
+    float2 *twl = vb + (size_t)F * M;                           // M
+    float *hs = reinterpret_cast<float *>(twl + M);             // p * M : hs[n*M + c] = h[(M-1-c) + n*M]
     const int hist_len = (p - 1) * M;
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    for (int e = threadIdx.x; e < p * M; e += 256) {
+        const int n = e / M, c = e - n * M;
+        hs[e] = h[(M - 1 - c) + n * M];
+    }
     for (size_t tile = blockIdx.x; tile * F < nframes; tile += gridDim.x) {
         const size_t f0 = tile * F;
         const int nf = (int)((nframes - f0) < (size_t)F ? (nframes - f0) : (size_t)F);
         const long long base = (long long)f0 * M - hist_len;
         const int nspan = (nf + p - 1) * M;
-        for (int u = threadIdx.x; u < nspan; u += 256)
-            xs[u] = load_hist(hist, hist_len, x, base + u, (long long)nframes * M);
+        const long long x_len = (long long)nframes * M;
+        if (base >= 0 && base + nspan <= x_len) {               // interior tile: straight coalesced copy
+            const float2 *src = x + base;
+            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = src[u];
+        } else {
+            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = load_hist(hist, hist_len, x, base + u, x_len);
+        }
         __syncthreads();
         for (int e = threadIdx.x; e < nf * M; e += 256) {
             const int f = e / M, c = e - f * M;
             float2 acc = make_float2(0.f, 0.f);
             // X[(f0+f-n)*M + c] sits at span offset (f + p-1 - n)*M + c
+            const float2 *xp = xs + (f + p - 1) * M + c;
             for (int n = 0; n < p; ++n) {
-                const float hv = h[(M - 1 - c) + n * M];
-                const float2 s = xs[(f + p - 1 - n) * M + c];
-                acc.x = fmaf(s.x, hv, acc.x);
-                acc.y = fmaf(s.y, hv, acc.y);
+                const float hv = hs[n * M + c];
+                const float2 sv = xp[-n * M];
+                acc.x = fmaf(sv.x, hv, acc.x);
+                acc.y = fmaf(sv.y, hv, acc.y);
             }
             va[e] = acc;
         }
         __syncthreads();
-        float2 *res = lds_dft_frames(va, vb, M, nf, fl, twM, 1, false);
+        float2 *res = POW2 ? lds_fft_pow2<-1>(va, vb, M, nf, plan, twl, 1)
+                           : lds_dft_frames(va, vb, M, nf, fl, twl, 1, false);
         for (int e = threadIdx.x; e < nf * M; e += 256) y[f0 * M + e] = res[e];
         __syncthreads();
     }
@@ -120,28 +137,31 @@ firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
 
 static constexpr size_t kChanLdsBudget = 60 * 1024;
 
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
                     const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
     // frames per tile: as many as fit the LDS budget (>= 1)
     int F = 4096 / M;
     if (F < 1) F = 1;
-    auto need = [&](int f) { return ((size_t)(f + p - 1) * M + 2 * (size_t)f * M) * sizeof(float2); };
+    const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
+    auto need = [&](int f) { return ((size_t)(f + p - 1) * M + 2 * (size_t)f * M) * sizeof(float2) + fixed; };
     while (F > 1 && need(F) > kChanLdsBudget) F /= 2;
     if (need(F) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch: M*p too large for LDS (%d x %d)", M, p);
-    static bool raised = false;
-    if (need(F) > 64 * 1024 && !raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
+    const bool pow2 = is_pow2(M);
+    const void *fn = pow2 ? reinterpret_cast<const void *>(firpfbch_kernel<true>)
+                          : reinterpret_cast<const void *>(firpfbch_kernel<false>);
+    if (need(F) > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t tiles = (nframes + F - 1) / F;
     const unsigned grid = (unsigned)(tiles < 65536 ? tiles : 65536);
-    firpfbch_kernel<<<grid, 256, need(F), st>>>(reinterpret_cast<const float2 *>(hist),
-                                               reinterpret_cast<const float2 *>(x), h, M, p,
-                                               reinterpret_cast<const float2 *>(twM),
-                                               factorize_small(M), reinterpret_cast<float2 *>(y),
-                                               nframes, F);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (pow2)
+        firpfbch_kernel<true><<<grid, 256, need(F), st>>>(fh, fx, h, M, p, ftw, FacList{0, {0}}, make_pow2_plan(M), fy, nframes, F);
+    else
+        firpfbch_kernel<false><<<grid, 256, need(F), st>>>(fh, fx, h, M, p, ftw, factorize_small(M), Pow2Plan{0, {0}}, fy, nframes, F);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -149,25 +169,35 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
 // ---------------------------------------------------------------------------------------------
 // firpfbch2 analyzer (optionally one rank's sub-band shard)
 // ---------------------------------------------------------------------------------------------
+template <bool POW2>
 __global__ void __launch_bounds__(256)
 firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                  const float *__restrict__ h, int M, int p, const float2 *__restrict__ twM,
-                 FacList fl, unsigned long long step0, int rank, int R,
+                 FacList fl, Pow2Plan plan, unsigned long long step0, int rank, int R,
                  float2 *__restrict__ y, size_t nsteps, int S) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M2 = M / 2, Mr = M / R;
     const int lead = (p - 1) * M + M2;                         // samples needed before a tile
     float2 *xs = reinterpret_cast<float2 *>(smem);             // lead + S*M2 samples
     float2 *va = xs + (size_t)lead + (size_t)S * M2;           // S * M
-    float2 *vb = va + (size_t)S * M;                           // S * Mr (fold) / Stockham partner
+    float2 *vb = va + (size_t)S * M;                           // S * M (fold / Stockham partner)
+    float2 *twl = vb + (size_t)S * M;                          // M
+    float *hs = reinterpret_cast<float *>(twl + M);            // p * M taps, natural order h[i + n*M]
     const float invM = 1.0f / (float)M;
     const long long x_len = (long long)nsteps * M2;
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    for (int e = threadIdx.x; e < p * M; e += 256) hs[e] = h[e];
     for (size_t tile = blockIdx.x; tile * S < nsteps; tile += gridDim.x) {
         const size_t s0 = tile * S;
         const int ns = (int)((nsteps - s0) < (size_t)S ? (nsteps - s0) : (size_t)S);
         const long long base = (long long)s0 * M2 - lead;
         const int nspan = lead + ns * M2;
-        for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = load_hist(hist, hist_len, x, base + u, x_len);
+        if (base >= 0 && base + nspan <= x_len) {
+            const float2 *src = x + base;
+            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = src[u];
+        } else {
+            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = load_hist(hist, hist_len, x, base + u, x_len);
+        }
         __syncthreads();
         for (int e = threadIdx.x; e < ns * M; e += 256) {
             const int sl = e / M, b = e - sl * M;
@@ -179,13 +209,14 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
             int i = b - (flag ? M2 : 0);
             if (i < 0) i += M;
             // newest sample of window b: local step (sl - back), span offset lead + (sl-back)*M2 + pos
-            const int top = lead + (sl - back) * M2 + pos;
+            const float2 *xp = xs + lead + (sl - back) * M2 + pos;
+            const float *hp = hs + i;
             float2 acc = make_float2(0.f, 0.f);
             for (int n = 0; n < p; ++n) {
-                const float hv = h[i + n * M];
-                const float2 s = xs[top - n * M];
-                acc.x = fmaf(s.x, hv, acc.x);
-                acc.y = fmaf(s.y, hv, acc.y);
+                const float hv = hp[n * M];
+                const float2 sv = xp[-n * M];
+                acc.x = fmaf(sv.x, hv, acc.x);
+                acc.y = fmaf(sv.y, hv, acc.y);
             }
             va[e] = acc;
         }
@@ -197,11 +228,11 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
                 const int sl = e / Mr, bq = e - sl * Mr;
                 float2 acc = make_float2(0.f, 0.f);
                 for (int a = 0; a < R; ++a) {
-                    float2 w = twM[((a * rank) % R) * Mr];     // W_R^{a r} = W_M^{a r M/R}
+                    float2 w = twl[((a * rank) % R) * Mr];     // W_R^{a r} = W_M^{a r M/R}
                     w.y = -w.y;
                     acc = cadd(acc, cmul(va[sl * M + Mr * a + bq], w));
                 }
-                float2 w2 = twM[(bq * rank) % M];
+                float2 w2 = twl[(bq * rank) % M];
                 w2.y = -w2.y;
                 vb[e] = cmul(acc, w2);
             }
@@ -209,7 +240,8 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
             srcb = vb;
             dstb = va;
         }
-        float2 *res = lds_dft_frames(srcb, dstb, Mr, ns, fl, twM, R, true);
+        float2 *res = POW2 ? lds_fft_pow2<+1>(srcb, dstb, Mr, ns, plan, twl, R)
+                           : lds_dft_frames(srcb, dstb, Mr, ns, fl, twl, R, true);
         for (int e = threadIdx.x; e < ns * Mr; e += 256) {
             const float2 v = res[e];
             y[s0 * Mr + e] = make_float2(v.x * invM, v.y * invM);
@@ -229,22 +261,26 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
     int S = 4096 / M;
     if (S < 1) S = 1;
-    auto need = [&](int s) { return (lead + (size_t)s * M2 + 2 * (size_t)s * M) * sizeof(float2); };
+    const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
+    auto need = [&](int s) { return (lead + (size_t)s * M2 + 2 * (size_t)s * M) * sizeof(float2) + fixed; };
     while (S > 1 && need(S) > kChanLdsBudget) S /= 2;
     if (need(S) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch2: M*m too large for LDS (%d x %d)", M, m);
-    static bool raised = false;
-    if (need(S) > 64 * 1024 && !raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
+    const int Mr = M / nranks;
+    const bool pow2 = is_pow2(Mr);
+    const void *fn = pow2 ? reinterpret_cast<const void *>(firpfbch2_kernel<true>)
+                          : reinterpret_cast<const void *>(firpfbch2_kernel<false>);
+    if (need(S) > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t tiles = (nsteps + S - 1) / S;
     const unsigned grid = (unsigned)(tiles < 65536 ? tiles : 65536);
-    firpfbch2_kernel<<<grid, 256, need(S), st>>>(reinterpret_cast<const float2 *>(hist), hist_len,
-                                                reinterpret_cast<const float2 *>(x), h, M, p,
-                                                reinterpret_cast<const float2 *>(twM),
-                                                factorize_small(M / nranks), (unsigned long long)step0,
-                                                rank, nranks, reinterpret_cast<float2 *>(y), nsteps, S);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (pow2)
+        firpfbch2_kernel<true><<<grid, 256, need(S), st>>>(fh, hist_len, fx, h, M, p, ftw, FacList{0, {0}}, make_pow2_plan(Mr),
+                                                          (unsigned long long)step0, rank, nranks, fy, nsteps, S);
+    else
+        firpfbch2_kernel<false><<<grid, 256, need(S), st>>>(fh, hist_len, fx, h, M, p, ftw, factorize_small(Mr), Pow2Plan{0, {0}},
+                                                           (unsigned long long)step0, rank, nranks, fy, nsteps, S);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }

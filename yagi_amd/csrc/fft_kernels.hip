@@ -9,7 +9,7 @@
 //                    each lane produces ONE output of a radix-R butterfly per pass by a direct
 //                    R-term sum with exact table twiddles (index arithmetic mod N), so every
 //                    radix, prime or not, takes the same code path (O(N * sum(R)) work).
-#include "fft_core.hpp"
+#include "fft_radix.hpp"
 #include "kernels.hpp"
 
 namespace yagi {
@@ -70,6 +70,36 @@ fft_lds_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__
     }
 }
 
+// Power-of-two N <= 8192 (other than 4096): a workgroup owns `nfr` consecutive transforms (so small
+// N still fills 256 lanes), radix-16/8/4/2 register butterflies, Stockham autosort through two LDS
+// buffers, twiddle table in LDS.  One HBM round trip: 16 B/point.
+template <int SIGN>
+__global__ void __launch_bounds__(256)
+fft_pow2_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *__restrict__ out,
+                const float2 *__restrict__ tw, size_t batch, int nfr, int tw_in_lds) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *bufA = reinterpret_cast<float2 *>(smem);
+    float2 *bufB = bufA + (size_t)nfr * N;
+    // the plan's table already carries the direction's sign (tw_is_forward = false below);
+    // it is copied to LDS unless the transform itself needs the room (N = 8192)
+    const float2 *twl = tw;
+    if (tw_in_lds) {
+        float2 *t = bufB + (size_t)nfr * N;
+        for (int e = threadIdx.x; e < N; e += 256) t[e] = tw[e];
+        twl = t;
+    }
+    for (size_t g = blockIdx.x; g * nfr < batch; g += gridDim.x) {
+        const size_t b0 = g * nfr;
+        const int nb = (int)((batch - b0) < (size_t)nfr ? (batch - b0) : (size_t)nfr);
+        const int total = nb * N;
+        __syncthreads();
+        for (int e = threadIdx.x; e < total; e += 256) bufA[e] = in[b0 * N + e];
+        __syncthreads();
+        float2 *res = lds_fft_pow2<SIGN>(bufA, bufB, N, nb, plan, twl, 1, false);
+        for (int e = threadIdx.x; e < total; e += 256) out[b0 * N + e] = res[e];
+    }
+}
+
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     if (batch == 0) return YAGI_OK;
     const float2 *fin = reinterpret_cast<const float2 *>(in);
@@ -85,6 +115,23 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         return YAGI_OK;
     }
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
+    if (p.n >= 2 && (p.n & (p.n - 1)) == 0) {
+        int nfr = 4096 / p.n;
+        if (nfr < 1) nfr = 1;
+        const int tw_in_lds = p.n <= 4096 ? 1 : 0;
+        const size_t lds2 = (2 * (size_t)nfr * p.n + (tw_in_lds ? (size_t)p.n : 0)) * sizeof(float2);
+        const size_t groups = (batch + nfr - 1) / nfr;
+        const unsigned grid2 = (unsigned)(groups < 32768 ? groups : 32768);
+        const void *fn = p.dir == YAGI_FFT_FORWARD ? reinterpret_cast<const void *>(fft_pow2_kernel<-1>)
+                                                   : reinterpret_cast<const void *>(fft_pow2_kernel<+1>);
+        if (lds2 > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (p.dir == YAGI_FFT_FORWARD)
+            fft_pow2_kernel<-1><<<grid2, 256, lds2, st>>>(p.n, make_pow2_plan(p.n), fin, fout, tw, batch, nfr, tw_in_lds);
+        else
+            fft_pow2_kernel<+1><<<grid2, 256, lds2, st>>>(p.n, make_pow2_plan(p.n), fin, fout, tw, batch, nfr, tw_in_lds);
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
     const size_t lds = 2 * (size_t)p.n * sizeof(float2);
     const unsigned grid = (unsigned)(batch < 16384 ? batch : 16384);
     int threads = 256;
