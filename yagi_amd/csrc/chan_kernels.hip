@@ -18,8 +18,9 @@
 //   sharded   : rank r of R keeps k = r + R*q:  fold Z[b'] = e^{+j2pi b' r/M} sum_a e^{+j2pi a r/R}
 //               V[(M/R)a + b'], then an (M/R)-point inverse DFT over b' (decimation in frequency),
 //               so each GPU writes only M/R outputs per step.
-// One workgroup owns a tile of frames: input tile + history staged in LDS once (8 B/sample from
-// HBM), branch dot products from LDS, the M-point DFTs as Stockham passes in LDS, coalesced
+// One workgroup owns a tile of frames.  firpfbch (small M, p up to 16): input tile + history staged in
+// LDS once (8 B/sample from HBM), branch dot products from LDS; firpfbch2 (M = 256: the history is
+// ~4 tiles long) reads samples straight from L1/L2 instead (measured faster, profiles/r01_notes.md); the M-point DFTs as Stockham passes in LDS, coalesced
 // [frame][channel] stores (8 or 16 B per input sample).  HBM-bound by construction.
 #include "fft_radix.hpp"
 #include "kernels.hpp"
@@ -135,7 +136,7 @@ firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
     }
 }
 
-static constexpr size_t kChanLdsBudget = 60 * 1024;
+static constexpr size_t kChanLdsBudget = 38 * 1024;   // <= 4 workgroups per CU
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -177,9 +178,7 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
                  float2 *__restrict__ y, size_t nsteps, int S) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M2 = M / 2, Mr = M / R;
-    const int lead = (p - 1) * M + M2;                         // samples needed before a tile
-    float2 *xs = reinterpret_cast<float2 *>(smem);             // lead + S*M2 samples
-    float2 *va = xs + (size_t)lead + (size_t)S * M2;           // S * M
+    float2 *va = reinterpret_cast<float2 *>(smem);             // S * M
     float2 *vb = va + (size_t)S * M;                           // S * M (fold / Stockham partner)
     float2 *twl = vb + (size_t)S * M;                          // M
     float *hs = reinterpret_cast<float *>(twl + M);            // p * M taps, natural order h[i + n*M]
@@ -187,18 +186,12 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
     const long long x_len = (long long)nsteps * M2;
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     for (int e = threadIdx.x; e < p * M; e += 256) hs[e] = h[e];
+    __syncthreads();
     for (size_t tile = blockIdx.x; tile * S < nsteps; tile += gridDim.x) {
         const size_t s0 = tile * S;
         const int ns = (int)((nsteps - s0) < (size_t)S ? (nsteps - s0) : (size_t)S);
-        const long long base = (long long)s0 * M2 - lead;
-        const int nspan = lead + ns * M2;
-        if (base >= 0 && base + nspan <= x_len) {
-            const float2 *src = x + base;
-            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = src[u];
-        } else {
-            for (int u = threadIdx.x; u < nspan; u += 256) xs[u] = load_hist(hist, hist_len, x, base + u, x_len);
-        }
-        __syncthreads();
+        // oldest sample any window of this tile needs: (s0 - 1)*M2 - (p-1)*M  (>= 0 for interior tiles)
+        const bool interior = (long long)s0 * M2 - M2 - (long long)(p - 1) * M >= 0;
         for (int e = threadIdx.x; e < ns * M; e += 256) {
             const int sl = e / M, b = e - sl * M;
             const unsigned long long sg = step0 + s0 + sl;     // global step index (parity = flag)
@@ -208,15 +201,26 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
             const int back = (flag == bpar) ? 0 : 1;           // steps since window b was last fed
             int i = b - (flag ? M2 : 0);
             if (i < 0) i += M;
-            // newest sample of window b: local step (sl - back), span offset lead + (sl-back)*M2 + pos
-            const float2 *xp = xs + lead + (sl - back) * M2 + pos;
+            // newest sample of window b: X index (s0 + sl - back)*M2 + pos; lanes hold consecutive b,
+            // i.e. a contiguous (descending) run of x; re-reads by later steps hit L1/L2
+            const long long top = ((long long)(s0 + sl) - back) * M2 + pos;
             const float *hp = hs + i;
             float2 acc = make_float2(0.f, 0.f);
-            for (int n = 0; n < p; ++n) {
-                const float hv = hp[n * M];
-                const float2 sv = xp[-n * M];
-                acc.x = fmaf(sv.x, hv, acc.x);
-                acc.y = fmaf(sv.y, hv, acc.y);
+            if (interior) {
+                const float2 *xp = x + top;
+                for (int n = 0; n < p; ++n) {
+                    const float hv = hp[n * M];
+                    const float2 sv = xp[-(long long)n * M];
+                    acc.x = fmaf(sv.x, hv, acc.x);
+                    acc.y = fmaf(sv.y, hv, acc.y);
+                }
+            } else {
+                for (int n = 0; n < p; ++n) {
+                    const float hv = hp[n * M];
+                    const float2 sv = load_hist(hist, hist_len, x, top - (long long)n * M, x_len);
+                    acc.x = fmaf(sv.x, hv, acc.x);
+                    acc.y = fmaf(sv.y, hv, acc.y);
+                }
             }
             va[e] = acc;
         }
@@ -262,7 +266,7 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     int S = 4096 / M;
     if (S < 1) S = 1;
     const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
-    auto need = [&](int s) { return (lead + (size_t)s * M2 + 2 * (size_t)s * M) * sizeof(float2) + fixed; };
+    auto need = [&](int s) { return 2 * (size_t)s * M * sizeof(float2) + fixed; };
     while (S > 1 && need(S) > kChanLdsBudget) S /= 2;
     if (need(S) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch2: M*m too large for LDS (%d x %d)", M, m);
     const int Mr = M / nranks;
