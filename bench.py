@@ -149,6 +149,15 @@ def main():
         except Exception as e:            # the checker must never hide a bench result
             parity = f"unavailable: {e}"
 
+    kernel_name = "fir_crcf_mfma_kernel<68, true>" if args.variant == 2 else "firfft_crcf_4096_slide_kernel"
+    traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/traffic.json)
+    try:
+        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        if tj.get("samples_per_launch") == n:
+            traffic = tj["kernels"][kernel_name]["hbm_bytes"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         samples = n * args.steps * world
         value = samples / elapsed / 1e6
@@ -171,9 +180,11 @@ def main():
                                    "fused, streaming complex f32 (BASELINE configs[1] feeding configs[2])",
                        "samples_per_step_per_gpu": n, "frames_per_step": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
-                       "kernel": "firfft_crcf_4096_slide_kernel", "variant": args.variant},
+                       "kernel": kernel_name, "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, bytes per launch; "
+                                           "profiles/traffic.json" if traffic else None,
                          "kernel_ms": round(kern_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
                          "note": "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32",

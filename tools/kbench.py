@@ -46,6 +46,16 @@ if "decim" in what:
     d = ya.FirDecimationFilter.new_kaiser("crcf", 4, 8, 60.0)
     d.set_stream(st.cuda_stream)
     cases["firdecim_crcf M=4 L=65"] = (lambda: d.execute_block_dev(x, n // 4, y), 10 * n)
+if "fft_big" in what:      # config C3: 65 536 transforms of 4096 points, 2 GiB in + 2 GiB out
+    nb = 65536 * 4096
+    xb = torch.empty(nb, dtype=torch.complex64, device=dev)
+    yb = torch.empty(nb, dtype=torch.complex64, device=dev)
+    ya.gen_complex_dev(0x59414749 + 3, nb, out=xb, stream=st.cuda_stream)
+    planb = ya.Fft(4096, ya.Direction.Forward)
+    cases["fft4096 x65536 (C3)"] = (lambda: planb.run_batch_dev(xb, yb, 65536, st.cuda_stream), 16 * nb)
+    BIG = {"fft4096 x65536 (C3)": nb}
+else:
+    BIG = {}
 for fn, _ in cases.values():
     fn()
 torch.cuda.synchronize()
@@ -61,4 +71,5 @@ for rnd in range(5):
         res[k].append(e0.elapsed_time(e1) / 10)
 for k, v in res.items():
     ms = float(np.median(v))
-    print(f"{k:28s} median {ms:8.4f} ms  min {min(v):8.4f}  {n / ms / 1e6:9.1f} Gsamples/s  {cases[k][1] / ms / 1e6:8.1f} GB/s algorithmic")
+    nn = BIG.get(k, n)
+    print(f"{k:28s} median {ms:8.4f} ms  min {min(v):8.4f}  {nn / ms / 1e6:9.1f} Gsamples/s  {cases[k][1] / ms / 1e6:8.1f} GB/s algorithmic")

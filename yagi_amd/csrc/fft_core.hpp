@@ -60,41 +60,51 @@ __device__ __forceinline__ constexpr int dft16_pos(int k) { return 4 * (k & 3) +
 // v[a] = x[256a + b].  `lds` is a kFft4096LdsFloat2 float2 buffer nobody else touches; `tw` is
 // the W_4096^m table (sign already per direction).  Output goes to out[k], k in [0,4096).
 // Contains 4 __syncthreads(); all 256 lanes must call it.
-template <int SIGN>
+template <int SIGN, bool GUARD = false>
 __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restrict__ lds,
                                                const float2 *__restrict__ tw,
                                                float2 *__restrict__ out) {
+    // GUARD lets a workgroup larger than 256 lanes call this: lanes >= 256 only join the barriers.
     const unsigned t = threadIdx.x;
+    const bool active = !GUARD || t < 256;
     // ---- pass 1 (lane b = t) ----
-    dft16<SIGN>(v);
+    if (active) {
+        dft16<SIGN>(v);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float2 z = v[dft16_pos(c)];
-        if (c) z = cmul(z, tw[(unsigned)(t * c)]);
-        lds[c * kEx1Stride + t] = z;
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul(z, tw[(unsigned)(t * c)]);
+            lds[c * kEx1Stride + t] = z;
+        }
     }
     __syncthreads();
     // ---- pass 2 (lane = c*16 + b') ----
     {
         const unsigned c = t >> 4, bp = t & 15;
+        if (active) {
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = lds[c * kEx1Stride + 16 * a + bp];
+            for (int a = 0; a < 16; ++a) v[a] = lds[c * kEx1Stride + 16 * a + bp];
+        }
         __syncthreads();                       // exchange-1 reads done before the buffer is reused
-        dft16<SIGN>(v);
+        if (active) {
+            dft16<SIGN>(v);
 #pragma unroll
-        for (int cp = 0; cp < 16; ++cp) {
-            float2 u = v[dft16_pos(cp)];
-            if (cp) u = cmul(u, tw[(unsigned)(16 * bp * cp)]);
-            lds[bp * kEx2Stride + cp * 16 + c] = u;
+            for (int cp = 0; cp < 16; ++cp) {
+                float2 u = v[dft16_pos(cp)];
+                if (cp) u = cmul(u, tw[(unsigned)(16 * bp * cp)]);
+                lds[bp * kEx2Stride + cp * 16 + c] = u;
+            }
         }
     }
     __syncthreads();
     // ---- pass 3 (lane = c + 16c') ----
+    if (active) {
 #pragma unroll
-    for (int bp = 0; bp < 16; ++bp) v[bp] = lds[bp * kEx2Stride + t];
-    dft16<SIGN>(v);
+        for (int bp = 0; bp < 16; ++bp) v[bp] = lds[bp * kEx2Stride + t];
+        dft16<SIGN>(v);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) out[t + 256 * d] = v[dft16_pos(d)];
+        for (int d = 0; d < 16; ++d) out[t + 256 * d] = v[dft16_pos(d)];
+    }
     __syncthreads();                           // LDS free for the caller's next transform
 }
 

@@ -62,16 +62,17 @@ __device__ __forceinline__ void stage_span(float2 *__restrict__ xs, const float2
         const float4 *src = reinterpret_cast<const float4 *>(x + first);
         const int npairs = (nspan + 2) >> 1;          // covers span indices -1 .. nspan
         // batches of 5 loads in flight per lane (bounded register footprint: 20 VGPRs)
-        for (int q0 = threadIdx.x; q0 < npairs; q0 += 5 * 256) {
+        const int nthr = blockDim.x;
+        for (int q0 = threadIdx.x; q0 < npairs; q0 += 5 * nthr) {
             float4 r[5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const int q = q0 + 256 * i;
+                const int q = q0 + nthr * i;
                 r[i] = src[q < npairs ? q : npairs - 1];
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const int q = q0 + 256 * i;
+                const int q = q0 + nthr * i;
                 const int u = 2 * q - 1;              // span index of r.xy ; r.zw is u + 1
                 if (q < npairs) {
                     if (u >= 0) xs[padded(u)] = make_float2(r[i].x, r[i].y);
@@ -81,7 +82,7 @@ __device__ __forceinline__ void stage_span(float2 *__restrict__ xs, const float2
         }
         return;
     }
-    for (int u = threadIdx.x; u < nspan; u += 256) {
+    for (int u = threadIdx.x; u < nspan; u += blockDim.x) {
         const long long idx = base + u;
         float2 v = make_float2(0.f, 0.f);
         if (idx >= 0) { if (idx < x_len) v = x[idx]; }
@@ -210,20 +211,27 @@ __device__ __forceinline__ void fir_task_mfma(f32x4 (&acc)[4], const float (&a)[
     const float *p = xsf + 2 * (T0 + 64 * seg + k + (T0 >> 4) + 4 * seg) + c;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // B operands are prefetched PF steps ahead (static ring in registers) so the MFMA stream never
-    // waits on an LDS round trip; the compiler turns the waits into counted lgkmcnt(N).
-    constexpr int PF = 8;
+    // B operands are prefetched PF steps ahead (static ring in registers) and the instruction order
+    // is pinned with sched_group_barrier (1 DS read, then the step's MFMAs) so the MFMA stream never
+    // waits on an LDS round trip: the compiler then emits counted lgkmcnt(N) waits.
+    constexpr int PF = 6;
     float bq[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) bq[i] = p[2 * (4 * i + (i >> 2))];
 #pragma unroll
     for (int sp = 0; sp < NS + 12; ++sp) {
         const float b = bq[sp % PF];
-        if (sp + PF < NS + 12) bq[sp % PF] = p[2 * (4 * (sp + PF) + ((sp + PF) >> 2))];
+        if (sp + PF < NS + 12) {
+            bq[sp % PF] = p[2 * (4 * (sp + PF) + ((sp + PF) >> 2))];
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+        }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int s = sp - 4 * tt;
-            if (s >= 0 && s < NS) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b, acc[tt], 0, 0, 0);
+            if (s >= 0 && s < NS) {
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b, acc[tt], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // then this MFMA
+            }
         }
     }
 }
@@ -241,8 +249,9 @@ __device__ __forceinline__ void store_task_mfma(const f32x4 (&acc)[4], float *__
         for (int r = 0; r < 4; ++r) p[2 * (16 * tt + r + tt)] = acc[tt][r] * scale;
 }
 
-template <int NS, bool FUSED>
-__global__ void __launch_bounds__(256)
+// NW = waves per workgroup: 4 (two tasks per wave) or 8 (one task per wave, half the accumulators).
+template <int NS, bool FUSED, int NW>
+__global__ void __launch_bounds__(64 * NW)
 fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                      const float *__restrict__ apack, int L, int Lp, float scale,
                      const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units) {
@@ -251,29 +260,48 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
     float a[NS];
     load_apack<NS>(a, apack);
     const int wave = threadIdx.x >> 6;
+    constexpr int NT = 8 / NW;                   // tasks per wave
     // FUSED: n_units = frames (tile == frame); else n_units = output samples
     const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
     const long long x_len = FUSED ? (long long)n_units * kTile : (long long)n_units;
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t o0 = tile * kTile;
+#ifndef YG_ABL_NOSTAGE
         stage_span(xs, win, x, (long long)o0 - (Lp - 1), kTile + Lp, L, x_len);
+#endif
         __syncthreads();
-        f32x4 acc0[4], acc1[4];
-        fir_task_mfma<NS>(acc0, a, reinterpret_cast<const float *>(xs), 512 * wave);
-        fir_task_mfma<NS>(acc1, a, reinterpret_cast<const float *>(xs), 512 * (wave + 4));
+        f32x4 acc[NT][4];
+#ifndef YG_ABL_NOMFMA
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            fir_task_mfma<NS>(acc[t], a, reinterpret_cast<const float *>(xs), 512 * (wave + NW * t));
+#else
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{a[q], a[q + 4], xs[threadIdx.x + q].x, 0.f};
+#endif
         __syncthreads();                         // all waves done reading the span: reuse it as output image
-        store_task_mfma(acc0, reinterpret_cast<float *>(xs), 512 * wave, scale);
-        store_task_mfma(acc1, reinterpret_cast<float *>(xs), 512 * (wave + 4), scale);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            store_task_mfma(acc[t], reinterpret_cast<float *>(xs), 512 * (wave + NW * t), scale);
         __syncthreads();
         if (FUSED) {
+            const bool active = (NW == 4) || threadIdx.x < 256;
             float2 v[16];
+            if (active) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
+                for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
+            }
             __syncthreads();
-            fft4096_passes<-1>(v, xs, tw, out + o0);
+            fft4096_passes<-1, (NW > 4)>(v, xs, tw, out + o0);
         } else {
             const int nt = (int)((n_units - o0) < (size_t)kTile ? (n_units - o0) : (size_t)kTile);
-            for (int o = threadIdx.x; o < nt; o += 256) out[o0 + o] = xs[padded(o)];
+#ifndef YG_ABL_NOSTORE
+            for (int o = threadIdx.x; o < nt; o += 64 * NW) out[o0 + o] = xs[padded(o)];
+#else
+            if (xs[padded(threadIdx.x)].x == 123.456f) out[o0 + threadIdx.x] = xs[padded(threadIdx.x)];
+#endif
             __syncthreads();
         }
     }
@@ -292,27 +320,30 @@ void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack) {
         }
 }
 
-template <int NS, bool FUSED>
+template <int NS, bool FUSED, int NW>
 static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
                          const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
     static bool raised = false;
-    YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED>), raised));
+    YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW>), raised));
     const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
     const unsigned grid = (unsigned)(ntiles < 65536 ? ntiles : 65536);
-    fir_crcf_mfma_kernel<NS, FUSED><<<grid, 256, slide_lds_bytes(Lp), st>>>(
+    fir_crcf_mfma_kernel<NS, FUSED, NW><<<grid, 64 * NW, slide_lds_bytes(Lp), st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, Lp, scale,
         reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
+#ifndef YG_MFMA_NW
+#define YG_MFMA_NW 4
+#endif
 template <bool FUSED>
 static int launch_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
                        const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
     switch (Lp) {
-        case 64: return launch_mfma_t<20, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
-        case 128: return launch_mfma_t<36, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
-        case 256: return launch_mfma_t<68, FUSED>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 64: return launch_mfma_t<20, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 128: return launch_mfma_t<36, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 256: return launch_mfma_t<68, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
     }
     return fail(YAGI_ERR_INTERNAL, "mfma FIR: unsupported padded length %d", Lp);
 }
