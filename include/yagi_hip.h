@@ -196,6 +196,37 @@ YAGI_FIR_API(rrrf, float, float)
 YAGI_FIR_API(crcf, yagi_cf32, float)
 YAGI_FIR_API(cccf, yagi_cf32, yagi_cf32)
 
+/* ---- FftFilt<T,Coeff>: src/filter/fftfilt.rs (overlap-add fast convolution, block n, FFT 2n) ------
+ *   create            create(h, n)                     :46-84   (h_len == 0 or n < h_len-1 -> CONFIG;
+ *                                                               additionally 2n <= 8192 in this engine)
+ *   reset             reset()                          :86-88
+ *   set_scale/get_scale                                :95-101  (internally scale/(2n), like the reference)
+ *   execute           execute(x, y)                    :103-138 (x.len() != n or y.len() != n -> CONFIG)
+ *   execute_blocks    `nblocks` consecutive execute() calls as one batch (device-friendly form)
+ *   get_length        get_length()                     :140-142
+ * y = overlap-add of IFFT(FFT([x;0]) * FFT([h;0])) * scale; for rrrf the real part is returned
+ * (FromComplex32 for f32, fftfilt.rs:16-20). */
+#define YAGI_FFTFILT_API(K, T, C)                                                                   \
+    typedef struct yagi_hip_fftfilt_##K##_s *yagi_hip_fftfilt_##K;                                  \
+    int yagi_hip_fftfilt_##K##_create(const C *h, size_t h_len, size_t n, yagi_hip_fftfilt_##K *q); \
+    int yagi_hip_fftfilt_##K##_destroy(yagi_hip_fftfilt_##K q);                                     \
+    int yagi_hip_fftfilt_##K##_clone(yagi_hip_fftfilt_##K q, yagi_hip_fftfilt_##K *out);            \
+    int yagi_hip_fftfilt_##K##_set_stream(yagi_hip_fftfilt_##K q, yagi_stream_t s);                 \
+    int yagi_hip_fftfilt_##K##_reset(yagi_hip_fftfilt_##K q);                                       \
+    int yagi_hip_fftfilt_##K##_set_scale(yagi_hip_fftfilt_##K q, C scale);                          \
+    int yagi_hip_fftfilt_##K##_get_scale(yagi_hip_fftfilt_##K q, C *scale);                         \
+    int yagi_hip_fftfilt_##K##_get_length(yagi_hip_fftfilt_##K q, size_t *h_len);                   \
+    int yagi_hip_fftfilt_##K##_execute(yagi_hip_fftfilt_##K q, const T *x, size_t nx, T *y,         \
+                                       size_t ny);                                                  \
+    int yagi_hip_fftfilt_##K##_execute_blocks(yagi_hip_fftfilt_##K q, const T *x, size_t nblocks,   \
+                                              T *y);                                                \
+    int yagi_hip_fftfilt_##K##_execute_blocks_dev(yagi_hip_fftfilt_##K q, const T *x_dev,           \
+                                                  size_t nblocks, T *y_dev);
+
+YAGI_FFTFILT_API(rrrf, float, float)
+YAGI_FFTFILT_API(crcf, yagi_cf32, float)
+YAGI_FFTFILT_API(cccf, yagi_cf32, yagi_cf32)
+
 /* crcf only: which block kernel execute_block uses.  0 = auto, 1 = general LDS-broadcast kernel
  * (fir_kernels.hip), 2 = register-sliding kernel (stream_kernels.hip).  Test / ablation knob. */
 int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);

@@ -121,6 +121,12 @@ def lib():
         L.yo_firpfbch2_destroy.argtypes = [vp]
         L.yo_firpfbch2_analyzer_execute.argtypes = [vp, vp, sz, vp]
         L.yo_stream_fir_fft.argtypes = [vp, vp, vp, sz, vp, vp]
+        L.yo_fftfilt_create.restype = vp
+        L.yo_fftfilt_create.argtypes = [C.c_int, vp, sz, sz]
+        L.yo_fftfilt_destroy.argtypes = [vp]
+        L.yo_fftfilt_reset.argtypes = [vp]
+        L.yo_fftfilt_set_scale.argtypes = [vp, fp, fp]
+        L.yo_fftfilt_execute.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -459,6 +465,37 @@ class FirPfbCh2:
         y = np.empty(ns * self.M, np.complex64)
         self.L.yo_firpfbch2_analyzer_execute(self.h, _p(x), ns, _p(y))
         return y.reshape(ns, self.M)
+
+
+class FftFilt:
+    """Restatement of FftFilt<T,Coeff> (fftfilt.rs:46-142); the two FFTs are the f64 definition."""
+
+    def __init__(self, kind, h, n):
+        self.kind, self.L, self.n = kind, lib(), n
+        self.tdt, self.cdt, code = KINDS[kind]
+        h = _as(h, self.cdt)
+        self.h = self.L.yo_fftfilt_create(code, _p(h), len(h), n)
+        if not self.h:
+            raise ValueError("config")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.yo_fftfilt_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.L.yo_fftfilt_reset(self.h)
+
+    def set_scale(self, s):
+        s = complex(s)
+        self.L.yo_fftfilt_set_scale(self.h, s.real, s.imag)
+
+    def execute(self, x):
+        x = _as(x, self.tdt)
+        assert len(x) == self.n
+        y = np.empty_like(x)
+        self.L.yo_fftfilt_execute(self.h, _p(x), _p(y))
+        return y
 
 
 def stream_fir_fft(h, scale, x, nfft):

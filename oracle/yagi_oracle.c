@@ -620,6 +620,58 @@ void yo_firpfbch2_analyzer_execute(yo_firpfbch2 *q, const cf32 *x, size_t nsteps
     free(X); free(Y);
 }
 
+/* ------------------------------------------------------------------------------------
+ * FftFilt<T,Coeff>  --  src/filter/fftfilt.rs:22-142 (overlap-add, block n, FFT size 2n).
+ * The reference's two transforms are rustfft calls (f32); here they are the f64 DFT
+ * definition rounded to f32 after each transform (same hand-off points as the reference's
+ * Complex32 buffers).  kind: 0 rrrf, 1 crcf, 2 cccf (x/y real for rrrf, h complex for cccf).
+ * ---------------------------------------------------------------------------------- */
+typedef struct { int kind; size_t h_len, n; cf32 *h_freq, *w, *tbuf, *fbuf; cf64 *tmp; cf32 scale; } yo_fftfilt;
+
+static void yo_dft_f32io(const cf32 *in, size_t n, int dir, cf32 *out, cf64 *tmp) {
+    yo_dft_f64(in, n, dir, tmp);
+    for (size_t i = 0; i < n; i++) { out[i].re = (float)tmp[i].re; out[i].im = (float)tmp[i].im; }
+}
+void yo_fftfilt_set_scale(yo_fftfilt *q, float re, float im) {          /* :95-97 */
+    float d = 2.0f * (float)q->n;
+    q->scale.re = re / d; q->scale.im = im / d;
+}
+yo_fftfilt *yo_fftfilt_create(int kind, const float *h, size_t h_len, size_t n) {   /* :46-84 */
+    if (h_len == 0 || n < h_len - 1 || n == 0) return NULL;
+    yo_fftfilt *q = (yo_fftfilt *)calloc(1, sizeof(*q));
+    q->kind = kind; q->h_len = h_len; q->n = n;
+    q->h_freq = (cf32 *)calloc(2 * n, sizeof(cf32)); q->w = (cf32 *)calloc(n, sizeof(cf32));
+    q->tbuf = (cf32 *)calloc(2 * n, sizeof(cf32)); q->fbuf = (cf32 *)calloc(2 * n, sizeof(cf32));
+    q->tmp = (cf64 *)calloc(2 * n, sizeof(cf64));
+    for (size_t i = 0; i < 2 * n; i++) {
+        if (i < h_len) { q->tbuf[i].re = kind == 2 ? h[2 * i] : h[i]; q->tbuf[i].im = kind == 2 ? h[2 * i + 1] : 0.0f; }
+        else q->tbuf[i] = CZERO;
+    }
+    yo_dft_f32io(q->tbuf, 2 * n, 0, q->h_freq, q->tmp);
+    yo_fftfilt_set_scale(q, 1.0f, 0.0f);
+    return q;
+}
+void yo_fftfilt_destroy(yo_fftfilt *q) {
+    if (q) { free(q->h_freq); free(q->w); free(q->tbuf); free(q->fbuf); free(q->tmp); free(q); }
+}
+void yo_fftfilt_reset(yo_fftfilt *q) { memset(q->w, 0, q->n * sizeof(cf32)); }      /* :86-88 */
+void yo_fftfilt_execute(yo_fftfilt *q, const float *x, float *y) {                  /* :103-138 */
+    const size_t n = q->n;
+    for (size_t i = 0; i < n; i++) {
+        if (q->kind == 0) { q->tbuf[i].re = x[i]; q->tbuf[i].im = 0.0f; }
+        else { q->tbuf[i].re = x[2 * i]; q->tbuf[i].im = x[2 * i + 1]; }
+    }
+    for (size_t i = n; i < 2 * n; i++) q->tbuf[i] = CZERO;
+    yo_dft_f32io(q->tbuf, 2 * n, 0, q->fbuf, q->tmp);
+    for (size_t i = 0; i < 2 * n; i++) q->fbuf[i] = c_mul(q->fbuf[i], q->h_freq[i]);
+    yo_dft_f32io(q->fbuf, 2 * n, 1, q->tbuf, q->tmp);
+    for (size_t i = 0; i < n; i++) {
+        cf32 v = c_mul(c_add(q->tbuf[i], q->w[i]), q->scale);
+        if (q->kind == 0) y[i] = v.re; else { y[2 * i] = v.re; y[2 * i + 1] = v.im; }
+    }
+    memcpy(q->w, q->tbuf + n, n * sizeof(cf32));
+}
+
 /* the headline stream: firfilt_crcf execute_block, output cut into
  * consecutive nfft-sample frames, forward FFT of each (f32 radix-4 plan above).
  * Used by tests (small) and as the timed cpu_baseline of bench.py. */

@@ -226,3 +226,30 @@ def test_generator_is_counter_based(oracle):
     assert abs(np.var(a.real) - 0.5) < 0.06 and abs(np.var(a.imag) - 0.5) < 0.06
     r = oracle.gen_real(42, 4000)
     assert abs(np.var(r) - 1.0) < 0.08
+
+
+# ---- fftfilt: filter/fftfilt.rs:150-330, data filter/test_data.rs (tol 1e-3) ------------------
+def _nextpow2(x):            # math/mod.rs:80-92
+    x -= 1
+    n = 0
+    while x > 0:
+        x >>= 1
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("case", ["h4x256", "h7x256", "h13x256", "h23x256"])
+def test_fftfilt_golden(oracle, kind, case):
+    g = load_golden("fftfilt")
+    h, x, y = (g[f"fftfilt_{kind}_data_{case}_{s}"] for s in "hxy")
+    n = 1 << _nextpow2(len(h) - 1)
+    q = oracle.FftFilt(kind, h, n)
+    got = np.concatenate([q.execute(x[i:i + n]) for i in range(0, len(x), n)])
+    np.testing.assert_allclose(got[:len(y)], y, atol=1e-3, rtol=0)
+    # fast convolution == direct form (the golden sets are firfilt outputs of the same h, x)
+    np.testing.assert_allclose(got[:len(y)], oracle.fir_block_f64(kind, h, x)[:len(y)], atol=1e-5)
+    with pytest.raises(ValueError):
+        oracle.FftFilt(kind, h[:0], 64)
+    with pytest.raises(ValueError):
+        oracle.FftFilt(kind, np.arange(9), 7)

@@ -28,7 +28,7 @@ from ._capi import cf32, lib
 __all__ = [
     "YagiError", "InternalError", "ConfigError", "ValueError_", "RangeError", "ModeError",
     "NoConvergenceError", "DeviceError", "Direction", "dotprod", "FirFilter", "FirDecimationFilter",
-    "FirPfbFilter", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
+    "FirPfbFilter", "FftFilt", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
     "fir_design_kaiser", "device_count", "synchronize", "gen_complex_dev", "gen_real_dev",
 ]
 
@@ -436,6 +436,45 @@ class FirPfbFilter(_FirBase):
         self.execute_select_dev(di, dx, x.size, dy)
         synchronize()
         return dy.to_numpy()
+
+
+class FftFilt(_FirBase):
+    """FftFilt<T,Coeff> (src/filter/fftfilt.rs): overlap-add fast convolution, block n, FFT size 2n."""
+
+    def __init__(self, kind, h, n):                          # create(h, n) :46-84
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_fftfilt_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(_ptr(h), h.size, n, C.byref(hd)))
+        self._h = hd
+        self.n = n
+
+    create = classmethod(lambda cls, kind, h, n: cls(kind, h, n))
+
+    def get_length(self):                                    # :140-142
+        n = C.c_size_t()
+        _check(self._fn("get_length")(self._h, C.byref(n)))
+        return n.value
+
+    def execute(self, x, y=None):                            # :103-138
+        x = _arr(x, self.T)
+        if y is None:
+            y = np.empty(self.n, self.T)
+        _check(self._fn("execute")(self._h, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def execute_blocks(self, x):
+        """consecutive execute() calls over len(x)/n blocks as one device batch"""
+        x = _arr(x, self.T)
+        if x.size % self.n:
+            raise ConfigError("input must hold a whole number of blocks")
+        y = np.empty_like(x)
+        _check(self._fn("execute_blocks")(self._h, _ptr(x), x.size // self.n, _ptr(y)))
+        return y
+
+    def execute_blocks_dev(self, x_dev, nblocks, y_dev):
+        _check(self._fn("execute_blocks_dev")(self._h, _devptr(x_dev), nblocks, _devptr(y_dev)))
 
 
 # ---- Fft (src/fft/mod.rs:33-69) ---------------------------------------------------------------

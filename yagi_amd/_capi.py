@@ -121,6 +121,19 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute_all_dev", vp, vp, sz, vp)
     _sig(p + "execute_select_dev", vp, vp, vp, sz, vp)
 
+    p = f"yagi_hip_fftfilt_{_k}_"
+    _sig(p + "create", vp, sz, sz, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "clone", vp, pvp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "reset", vp)
+    _sig(p + "set_scale", vp, _Cc)
+    _sig(p + "get_scale", vp, vp)
+    _sig(p + "get_length", vp, C.POINTER(sz))
+    _sig(p + "execute", vp, vp, sz, vp, sz)
+    _sig(p + "execute_blocks", vp, vp, sz, vp)
+    _sig(p + "execute_blocks_dev", vp, vp, sz, vp)
+
 _sig("yagi_hip_firfilt_crcf_set_kernel", vp, ci)
 
 _sig("yagi_hip_fft_create", sz, ci, pvp)

@@ -898,6 +898,171 @@ int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n
 
 }  // extern "C"
 
+// ---- FftFilt ---------------------------------------------------------------------------------------
+namespace yagi {
+
+static cf32 cx_of(float v) { return cf32{v, 0.0f}; }
+static cf32 cx_of(cf32 v) { return v; }
+static float div_scalar(float s, float d) { return s / d; }
+static cf32 div_scalar(cf32 s, float d) { return cf32{s.re / d, s.im / d}; }
+static float mul_scalar(float s, float d) { return s * d; }
+static cf32 mul_scalar(cf32 s, float d) { return cf32{s.re * d, s.im * d}; }
+
+template <class K>
+struct FftFiltObj {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    std::vector<C> h;
+    int n = 0;
+    C scale = one_of<C>();          // stored divided by 2n like the reference (fftfilt.rs:95-97)
+    FftPlan fwd, bwd;
+    DevBuf hfreq;                   // FFT{[h;0]}, 2n points
+    DevBuf w[2];                    // overlap tail, n points, ping-pong
+    int cur = 0;
+    DevBuf tbuf, fbuf;              // [nblocks][2n] time / frequency buffers
+    Workspace ws;
+
+    int init(const C *hh, size_t h_len, size_t nn) {
+        if (h_len == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
+        if (nn < h_len - 1) return fail(YAGI_ERR_CONFIG, "block length must be greater than h_len-1 (%zu)", h_len - 1);
+        if (nn == 0) return fail(YAGI_ERR_CONFIG, "block length must be greater than zero");
+        if (2 * nn > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "block length %zu not supported (2n <= %d)", nn, kFftMaxLds);
+        YG_TRY(require_device());
+        h.assign(hh, hh + h_len);
+        n = (int)nn;
+        YG_TRY(fft_plan_init(fwd, 2 * nn, YAGI_FFT_FORWARD));
+        YG_TRY(fft_plan_init(bwd, 2 * nn, YAGI_FFT_BACKWARD));
+        std::vector<cf32> tb(2 * nn, cf32{0.f, 0.f});
+        for (size_t i = 0; i < h_len && i < 2 * nn; ++i) tb[i] = cx_of(h[i]);
+        YG_TRY(tbuf.alloc(2 * nn * sizeof(cf32)));
+        YG_TRY(hfreq.alloc(2 * nn * sizeof(cf32)));
+        YG_TRY(upload(tbuf.p, tb.data(), 2 * nn * sizeof(cf32), st));
+        YG_TRY(launch_fft_batch(fwd.d, tbuf.as<cf32>(), hfreq.as<cf32>(), 1, st));
+        YG_TRY(w[0].alloc(nn * sizeof(cf32)));
+        YG_TRY(w[1].alloc(nn * sizeof(cf32)));
+        scale = div_scalar(one_of<C>(), 2.0f * (float)n);
+        return reset();
+    }
+    int reset() {
+        YG_HIP(hipMemsetAsync(w[cur].p, 0, (size_t)n * sizeof(cf32), st));
+        return YAGI_OK;
+    }
+    int blocks_dev(const T *x, size_t nblocks, T *y) {
+        if (nblocks == 0) return YAGI_OK;
+        const size_t n2 = 2 * (size_t)n;
+        YG_TRY(tbuf.ensure(nblocks * n2 * sizeof(cf32)));
+        YG_TRY(fbuf.ensure(nblocks * n2 * sizeof(cf32)));
+        YG_TRY(launch_fftfilt_pad<T>(x, n, nblocks, tbuf.as<cf32>(), st));
+        YG_TRY(launch_fft_batch(fwd.d, tbuf.as<cf32>(), fbuf.as<cf32>(), nblocks, st));
+        YG_TRY(launch_fftfilt_mul(fbuf.as<cf32>(), hfreq.as<cf32>(), (int)n2, nblocks, st));
+        YG_TRY(launch_fft_batch(bwd.d, fbuf.as<cf32>(), tbuf.as<cf32>(), nblocks, st));
+        YG_TRY((launch_fftfilt_ola<T, C>(tbuf.as<cf32>(), w[cur].as<cf32>(), n, nblocks, scale, y,
+                                         w[1 - cur].as<cf32>(), st)));
+        cur = 1 - cur;
+        return YAGI_OK;
+    }
+    int blocks_host(const T *x, size_t nblocks, T *y) {
+        if (nblocks == 0) return YAGI_OK;
+        const size_t bytes = nblocks * (size_t)n * sizeof(T);
+        YG_TRY(ws.x.ensure(bytes));
+        YG_TRY(ws.y.ensure(bytes));
+        YG_TRY(upload(ws.x.p, x, bytes, st));
+        YG_TRY(blocks_dev(ws.x.as<T>(), nblocks, ws.y.as<T>()));
+        return download(y, ws.y.p, bytes, st);
+    }
+};
+
+}  // namespace yagi
+
+#define YAGI_FFTFILT_IMPL(K, KT, T, C)                                                              \
+    struct yagi_hip_fftfilt_##K##_s : FftFiltObj<KT> {};                                            \
+    extern "C" {                                                                                    \
+    int yagi_hip_fftfilt_##K##_create(const C *h, size_t h_len, size_t n, yagi_hip_fftfilt_##K *q) {\
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_fftfilt_##K##_s>();                                      \
+        YG_TRY(o->init(h, h_len, n));                                                               \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_destroy(yagi_hip_fftfilt_##K q) {                                    \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_clone(yagi_hip_fftfilt_##K q, yagi_hip_fftfilt_##K *out) {           \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        auto o = std::make_unique<yagi_hip_fftfilt_##K##_s>();                                      \
+        o->st = q->st;                                                                              \
+        YG_TRY(o->init(q->h.data(), q->h.size(), (size_t)q->n));                                    \
+        o->scale = q->scale;                                                                        \
+        YG_HIP(hipMemcpyAsync(o->w[o->cur].p, q->w[q->cur].p, (size_t)q->n * sizeof(cf32),          \
+                              hipMemcpyDeviceToDevice, q->st));                                     \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_set_stream(yagi_hip_fftfilt_##K q, yagi_stream_t s) {                \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_reset(yagi_hip_fftfilt_##K q) {                                      \
+        CHECK_Q(q);                                                                                 \
+        return q->reset();                                                                          \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_set_scale(yagi_hip_fftfilt_##K q, C scale) {                         \
+        CHECK_Q(q);                                                                                 \
+        q->scale = div_scalar(scale, 2.0f * (float)q->n);                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_get_scale(yagi_hip_fftfilt_##K q, C *scale) {                        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(scale);                                                                           \
+        *scale = mul_scalar(q->scale, 2.0f * (float)q->n);                                          \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_get_length(yagi_hip_fftfilt_##K q, size_t *h_len) {                  \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(h_len);                                                                           \
+        *h_len = q->h.size();                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_execute(yagi_hip_fftfilt_##K q, const T *x, size_t nx, T *y,         \
+                                       size_t ny) {                                                 \
+        CHECK_Q(q);                                                                                 \
+        if (nx != (size_t)q->n || ny != (size_t)q->n)                                               \
+            return fail(YAGI_ERR_CONFIG, "input and output lengths must match filter block size");  \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->blocks_host(x, 1, y);                                                             \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_execute_blocks(yagi_hip_fftfilt_##K q, const T *x, size_t nblocks,   \
+                                              T *y) {                                               \
+        CHECK_Q(q);                                                                                 \
+        if (nblocks == 0) return YAGI_OK;                                                           \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->blocks_host(x, nblocks, y);                                                       \
+    }                                                                                               \
+    int yagi_hip_fftfilt_##K##_execute_blocks_dev(yagi_hip_fftfilt_##K q, const T *x,               \
+                                                  size_t nblocks, T *y) {                           \
+        CHECK_Q(q);                                                                                 \
+        if (nblocks == 0) return YAGI_OK;                                                           \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->blocks_dev(x, nblocks, y);                                                        \
+    }                                                                                               \
+    }
+
+YAGI_FFTFILT_IMPL(rrrf, RRRF, float, float)
+YAGI_FFTFILT_IMPL(crcf, CRCF, yagi_cf32, float)
+YAGI_FFTFILT_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
+
 // ---- fused firfilt_crcf -> FFT stream ------------------------------------------------------------------
 struct yagi_hip_firfft_crcf_s : FirFft {};
 

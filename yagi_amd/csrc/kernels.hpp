@@ -72,6 +72,14 @@ constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-ke
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st);
 int launch_fft_shift(cf32 *buf, size_t n, size_t batch, hipStream_t st);
 
+// ---- fftfilt_kernels.hip (FftFilt, src/filter/fftfilt.rs:103-138) ------------------------------------
+template <class T>
+int launch_fftfilt_pad(const T *x, int n, size_t nblocks, cf32 *time, hipStream_t st);
+int launch_fftfilt_mul(cf32 *freq, const cf32 *hf, int n2, size_t nblocks, hipStream_t st);
+template <class T, class C>
+int launch_fftfilt_ola(const cf32 *t, const cf32 *w, int n, size_t nblocks, C scale, T *y, cf32 *w_next,
+                       hipStream_t st);
+
 // ---- chan_kernels.hip ----------------------------------------------------------------------
 // firpfbch analyzer: hist = the (p-1)*M samples preceding x[0] (oldest first).
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
