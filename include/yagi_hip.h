@@ -227,6 +227,44 @@ YAGI_FFTFILT_API(rrrf, float, float)
 YAGI_FFTFILT_API(crcf, yagi_cf32, float)
 YAGI_FFTFILT_API(cccf, yagi_cf32, yagi_cf32)
 
+/* ---- FirInterpolationFilter<T,Coeff>: src/filter/fir/firinterp.rs (polyphase interpolator) ---------
+ *   create           new(interp, h, h_len)        :36-60   (interp < 2 or h_len < interp -> CONFIG; taps
+ *                                                          zero-padded to a multiple of interp)
+ *   create_kaiser    new_kaiser(interp, m, as_)   :73-90   (uses the first 2*interp*m taps)
+ *   create_linear    new_linear(interp)           :135-147
+ *   create_window    new_window(interp, m)        :159-174
+ *   execute          execute(x, &mut y[..interp]) :224-231 (push x, then every branch in order)
+ *   execute_block    execute_block(x, y)          :239-244 (y holds n*interp samples)
+ *   flush            flush(y)                     :251-253 (execute with a zero input)
+ *   reset / get_interp_rate / get_sub_len / set_scale / get_scale   :177-215
+ * Device form: firpfb_all_kernel (all branches per pushed sample, output n-major). */
+#define YAGI_FIRINTERP_API(K, T, C)                                                                 \
+    typedef struct yagi_hip_firinterp_##K##_s *yagi_hip_firinterp_##K;                              \
+    int yagi_hip_firinterp_##K##_create(size_t interp, const C *h, size_t h_len,                    \
+                                        yagi_hip_firinterp_##K *q);                                 \
+    int yagi_hip_firinterp_##K##_create_kaiser(size_t interp, size_t m, float as_,                  \
+                                               yagi_hip_firinterp_##K *q);                          \
+    int yagi_hip_firinterp_##K##_create_linear(size_t interp, yagi_hip_firinterp_##K *q);           \
+    int yagi_hip_firinterp_##K##_create_window(size_t interp, size_t m, yagi_hip_firinterp_##K *q); \
+    int yagi_hip_firinterp_##K##_destroy(yagi_hip_firinterp_##K q);                                 \
+    int yagi_hip_firinterp_##K##_clone(yagi_hip_firinterp_##K q, yagi_hip_firinterp_##K *out);      \
+    int yagi_hip_firinterp_##K##_set_stream(yagi_hip_firinterp_##K q, yagi_stream_t s);             \
+    int yagi_hip_firinterp_##K##_reset(yagi_hip_firinterp_##K q);                                   \
+    int yagi_hip_firinterp_##K##_get_interp_rate(yagi_hip_firinterp_##K q, size_t *interp);         \
+    int yagi_hip_firinterp_##K##_get_sub_len(yagi_hip_firinterp_##K q, size_t *h_sub_len);          \
+    int yagi_hip_firinterp_##K##_set_scale(yagi_hip_firinterp_##K q, C scale);                      \
+    int yagi_hip_firinterp_##K##_get_scale(yagi_hip_firinterp_##K q, C *scale);                     \
+    int yagi_hip_firinterp_##K##_execute(yagi_hip_firinterp_##K q, T x, T *y, size_t ny);           \
+    int yagi_hip_firinterp_##K##_execute_block(yagi_hip_firinterp_##K q, const T *x, size_t nx,     \
+                                               T *y, size_t ny);                                    \
+    int yagi_hip_firinterp_##K##_execute_block_dev(yagi_hip_firinterp_##K q, const T *x_dev,        \
+                                                   size_t n, T *y_dev);                             \
+    int yagi_hip_firinterp_##K##_flush(yagi_hip_firinterp_##K q, T *y, size_t ny);
+
+YAGI_FIRINTERP_API(rrrf, float, float)
+YAGI_FIRINTERP_API(crcf, yagi_cf32, float)
+YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
+
 /* crcf only: which block kernel execute_block uses.  0 = auto, 1 = general LDS-broadcast kernel
  * (fir_kernels.hip), 2 = register-sliding kernel (stream_kernels.hip).  Test / ablation knob. */
 int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);

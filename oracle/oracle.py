@@ -355,6 +355,41 @@ class FirPfbFilter(_Obj):
         return y
 
 
+class FirInterpolationFilter:
+    """Restatement of FirInterpolationFilter<T,Coeff> (firinterp.rs:36-60,177-253): zero-pad the taps
+    to a multiple of interp, build a FirPfbFilter, execute = push then every branch in order."""
+
+    def __init__(self, kind, interp, h, h_len=None):
+        cdt = KINDS[kind][1]
+        h = _as(h, cdt)
+        h_len = len(h) if h_len is None else h_len
+        if interp < 2 or h_len < interp:
+            raise ValueError("config")
+        sub = 0
+        while interp * sub < h_len:
+            sub += 1
+        hp = np.zeros(interp * sub, cdt)
+        hp[:h_len] = h[:h_len]
+        self.kind, self.interp, self.h_sub_len = kind, interp, sub
+        self.bank = FirPfbFilter(kind, interp, hp, len(hp))
+
+    def set_scale(self, s):
+        self.bank.set_scale(s)
+
+    def reset(self):
+        self.bank.reset()
+
+    def execute(self, x):
+        self.bank.push(x)
+        return np.array([self.bank.execute(i) for i in range(self.interp)], dtype=self.bank.tdt)
+
+    def execute_block(self, xs):
+        return np.concatenate([self.execute(v) for v in xs])
+
+    def flush(self):
+        return self.execute(0.0)
+
+
 def fir_block_f64(kind, h, x, M=1, n=None, scale=1.0):
     """f64 truth: y[i] = scale * sum_k h[k] x[i*M-k], zero history."""
     tdt, cdt, code = KINDS[kind]

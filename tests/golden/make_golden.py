@@ -16,6 +16,7 @@ outputs.  Sources (all relative to the reference root):
   src/filter/test_data.rs:3-6393               FFTFILT_{RRRF,CRCF,CCCF}_DATA_H*X256_{H,X,Y}
   src/dotprod/mod.rs:341-655                   inline h/x/test vectors of the rand/struct tests
   src/filter/fir/firpfb.rs:318-346             firpfb impulse-response vector
+  src/filter/fir/firinterp.rs:277-387          firinterp_{rrrf,crcf}_generic h / x / test
 """
 import re
 import sys
@@ -104,6 +105,25 @@ def firpfb_vector(path: Path) -> dict:
     return out
 
 
+def firinterp_vectors(path: Path) -> dict:
+    """firinterp.rs:277-387: inline h / x / test of the two *_generic known-answer tests"""
+    txt = path.read_text()
+    out = {}
+    for kind in ("rrrf", "crcf"):
+        i0 = txt.index(f"fn test_firinterp_{kind}_generic")
+        body = txt[i0: txt.index("#[test]", i0)]
+        for var, ty1, ty2, abody in LET_ARR_RE.findall(body):
+            if var in ("h", "x", "test"):
+                ty = ty1 or ty2
+                out[f"firinterp_{kind}_generic__{var}"] = parse_body(abody, "Complex" in ty)
+        # the rrrf test spells x inline without a type annotation
+        m = re.search(r"let\s+x\s*=\s*\[([^\]]*)\];", body)
+        if m and f"firinterp_{kind}_generic__x" not in out:
+            out[f"firinterp_{kind}_generic__x"] = parse_body(m.group(1), False)
+        assert {f"firinterp_{kind}_generic__{v}" for v in ("h", "x", "test")} <= set(out), (kind, out.keys())
+    return out
+
+
 def main():
     ref = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     src = ref / "src"
@@ -114,6 +134,7 @@ def main():
         "fftfilt": const_tables(src / "filter/test_data.rs"),
         "dotprod": dotprod_vectors(src / "dotprod/mod.rs"),
         "firpfb": firpfb_vector(src / "filter/fir/firpfb.rs"),
+        "firinterp": firinterp_vectors(src / "filter/fir/firinterp.rs"),
     }
     for name, d in sets.items():
         assert d, name

@@ -253,3 +253,17 @@ def test_fftfilt_golden(oracle, kind, case):
         oracle.FftFilt(kind, h[:0], 64)
     with pytest.raises(ValueError):
         oracle.FftFilt(kind, np.arange(9), 7)
+
+
+# ---- firinterp: firinterp.rs:277-387 (*_generic, tol 1e-6) -------------------------------------
+@pytest.mark.parametrize("kind", ["rrrf", "crcf"])
+def test_firinterp_generic(oracle, kind):
+    g = load_golden("firinterp")
+    h, x, test = (g[f"firinterp_{kind}_generic__{s}"] for s in ("h", "x", "test"))
+    q = oracle.FirInterpolationFilter(kind, 4, h)
+    y = np.concatenate([q.execute(v) for v in x])
+    np.testing.assert_allclose(y, test, atol=1e-6, rtol=0)
+    with pytest.raises(ValueError):
+        oracle.FirInterpolationFilter(kind, 1, h)
+    with pytest.raises(ValueError):
+        oracle.FirInterpolationFilter(kind, 12, h)

@@ -28,7 +28,7 @@ from ._capi import cf32, lib
 __all__ = [
     "YagiError", "InternalError", "ConfigError", "ValueError_", "RangeError", "ModeError",
     "NoConvergenceError", "DeviceError", "Direction", "dotprod", "FirFilter", "FirDecimationFilter",
-    "FirPfbFilter", "FftFilt", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
+    "FirPfbFilter", "FirInterpolationFilter", "FftFilt", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
     "fir_design_kaiser", "device_count", "synchronize", "gen_complex_dev", "gen_real_dev",
 ]
 
@@ -436,6 +436,69 @@ class FirPfbFilter(_FirBase):
         self.execute_select_dev(di, dx, x.size, dy)
         synchronize()
         return dy.to_numpy()
+
+
+class FirInterpolationFilter(_FirBase):
+    """FirInterpolationFilter<T,Coeff> (src/filter/fir/firinterp.rs)."""
+
+    def __init__(self, kind, interp, h, h_len=None):         # new(interp, h, h_len) :36-60
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firinterp_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(interp, _ptr(h), h.size if h_len is None else h_len, C.byref(hd)))
+        self._h = hd
+
+    @classmethod
+    def _from(cls, kind, creator, *args):
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_firinterp_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn(creator)(*args, C.byref(hd)))
+        self._h = hd
+        return self
+
+    @classmethod
+    def new_kaiser(cls, kind, interp, m, as_):               # :73-90
+        return cls._from(kind, "create_kaiser", interp, m, as_)
+
+    @classmethod
+    def new_linear(cls, kind, interp):                       # :135-147
+        return cls._from(kind, "create_linear", interp)
+
+    @classmethod
+    def new_window(cls, kind, interp, m):                    # :159-174
+        return cls._from(kind, "create_window", interp, m)
+
+    def get_interp_rate(self):                               # :186-188
+        n = C.c_size_t()
+        _check(self._fn("get_interp_rate")(self._h, C.byref(n)))
+        return n.value
+
+    def get_sub_len(self):                                   # :195-197
+        n = C.c_size_t()
+        _check(self._fn("get_sub_len")(self._h, C.byref(n)))
+        return n.value
+
+    def execute(self, x):                                    # :224-231 -> interp outputs
+        y = np.empty(self.get_interp_rate(), self.T)
+        _check(self._fn("execute")(self._h, _byval(x, self._Tc), _ptr(y), y.size))
+        return y
+
+    def execute_block(self, x):                              # :239-244 -> n*interp outputs
+        x = _arr(x, self.T)
+        y = np.empty(x.size * self.get_interp_rate(), self.T)
+        _check(self._fn("execute_block")(self._h, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def execute_block_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def flush(self):                                         # :251-253
+        y = np.empty(self.get_interp_rate(), self.T)
+        _check(self._fn("flush")(self._h, _ptr(y), y.size))
+        return y
 
 
 class FftFilt(_FirBase):

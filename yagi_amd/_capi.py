@@ -121,6 +121,23 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute_all_dev", vp, vp, sz, vp)
     _sig(p + "execute_select_dev", vp, vp, vp, sz, vp)
 
+    p = f"yagi_hip_firinterp_{_k}_"
+    _sig(p + "create", sz, vp, sz, pvp)
+    _sig(p + "create_kaiser", sz, sz, f32, pvp)
+    _sig(p + "create_linear", sz, pvp)
+    _sig(p + "create_window", sz, sz, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "clone", vp, pvp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "reset", vp)
+    _sig(p + "get_interp_rate", vp, C.POINTER(sz))
+    _sig(p + "get_sub_len", vp, C.POINTER(sz))
+    _sig(p + "set_scale", vp, _Cc)
+    _sig(p + "get_scale", vp, vp)
+    _sig(p + "execute", vp, _T, vp, sz)
+    _sig(p + "execute_block", vp, vp, sz, vp, sz)
+    _sig(p + "execute_block_dev", vp, vp, sz, vp)
+    _sig(p + "flush", vp, vp, sz)
     p = f"yagi_hip_fftfilt_{_k}_"
     _sig(p + "create", vp, sz, sz, pvp)
     _sig(p + "destroy", vp)

@@ -898,6 +898,187 @@ int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n
 
 }  // extern "C"
 
+// ---- FirInterpolationFilter (src/filter/fir/firinterp.rs): a FirPfb bank run over every branch -------
+namespace yagi {
+
+template <class K>
+struct FirInterp {
+    using T = typename K::T;
+    using C = typename K::C;
+    FirPfb<K> bank;
+    int interp = 0, hs = 0;
+
+    int init(size_t m, const C *h, size_t h_len) {
+        if (m < 2) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");
+        if (h_len < m) return fail(YAGI_ERR_CONFIG, "filter length cannot be less than interp factor");
+        size_t sub = 0;
+        while (m * sub < h_len) ++sub;                       // firinterp.rs:44-47
+        std::vector<C> hp(m * sub, C{});
+        for (size_t i = 0; i < h_len; ++i) hp[i] = h[i];
+        YG_TRY(bank.init(m, hp.data(), hp.size()));
+        interp = (int)m;
+        hs = (int)sub;
+        return YAGI_OK;
+    }
+    // n inputs -> n*interp outputs (device pointers)
+    int block_dev(const T *x, size_t n, T *y) {
+        YG_TRY(bank.w.flush(bank.st));
+        YG_TRY((launch_firpfb_all<K>(bank.w.dev(), x, bank.taps.template as<C>(), bank.nf, bank.Ls,
+                                     bank.scale, y, n, bank.st)));
+        return bank.w.advance(x, n, bank.st);
+    }
+    int block_host(const T *x, size_t n, T *y) {
+        if (n == 0) return YAGI_OK;
+        YG_TRY(bank.ws.x.ensure(n * sizeof(T)));
+        YG_TRY(bank.ws.y.ensure(n * (size_t)interp * sizeof(T)));
+        YG_TRY(upload(bank.ws.x.p, x, n * sizeof(T), bank.st));
+        YG_TRY(block_dev(bank.ws.x.template as<T>(), n, bank.ws.y.template as<T>()));
+        return download(y, bank.ws.y.p, n * (size_t)interp * sizeof(T), bank.st);
+    }
+};
+
+}  // namespace yagi
+
+#define YAGI_FIRINTERP_IMPL(K, KT, T, C)                                                            \
+    struct yagi_hip_firinterp_##K##_s : FirInterp<KT> {};                                           \
+    extern "C" {                                                                                    \
+    int yagi_hip_firinterp_##K##_create(size_t interp, const C *h, size_t h_len,                    \
+                                        yagi_hip_firinterp_##K *q) {                                \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_firinterp_##K##_s>();                                    \
+        YG_TRY(o->init(interp, h, h_len));                                                          \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_create_kaiser(size_t interp, size_t m, float as_,                  \
+                                               yagi_hip_firinterp_##K *q) {                         \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (interp < 2) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
+        if (m == 0) return fail(YAGI_ERR_CONFIG, "filter delay must be greater than 0");            \
+        if (as_ < 0.0f) return fail(YAGI_ERR_CONFIG, "stop-band attenuation must be positive");     \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(2 * interp * m + 1, 0.5f / (float)interp, as_, 0.0f, hf));             \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
+        return yagi_hip_firinterp_##K##_create(interp, hc.data(), hc.size() - 1, q);                \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_create_linear(size_t interp, yagi_hip_firinterp_##K *q) {          \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (interp < 1) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
+        std::vector<C> hc(2 * interp);                                                              \
+        for (size_t i = 0; i < interp; ++i) {                                                       \
+            hc[i] = to_c((float)i / (float)interp, (C *)nullptr);                                   \
+            hc[interp + i] = to_c(1.0f - (float)i / (float)interp, (C *)nullptr);                   \
+        }                                                                                           \
+        return yagi_hip_firinterp_##K##_create(interp, hc.data(), hc.size(), q);                    \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_create_window(size_t interp, size_t m, yagi_hip_firinterp_##K *q) {\
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (interp < 1) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
+        if (m < 1) return fail(YAGI_ERR_CONFIG, "filter semi-length must be greater than 0");       \
+        const size_t hl = 2 * m * interp;                                                           \
+        std::vector<C> hc(hl);                                                                      \
+        for (size_t i = 0; i < hl; ++i) {                                                           \
+            const float sv = std::sin(3.14159265358979323846f * (float)i / (float)(2 * m * interp));\
+            hc[i] = to_c(sv * sv, (C *)nullptr);                                                    \
+        }                                                                                           \
+        return yagi_hip_firinterp_##K##_create(interp, hc.data(), hl, q);                           \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_destroy(yagi_hip_firinterp_##K q) {                                \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_clone(yagi_hip_firinterp_##K q, yagi_hip_firinterp_##K *out) {     \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        YG_TRY(q->bank.w.flush(q->bank.st));                                                        \
+        auto o = std::make_unique<yagi_hip_firinterp_##K##_s>();                                    \
+        o->interp = q->interp;                                                                      \
+        o->hs = q->hs;                                                                              \
+        o->bank.st = q->bank.st;                                                                    \
+        o->bank.nf = q->bank.nf;                                                                    \
+        o->bank.Ls = q->bank.Ls;                                                                    \
+        o->bank.hb = q->bank.hb;                                                                    \
+        o->bank.scale = q->bank.scale;                                                              \
+        YG_TRY(o->bank.taps.alloc(o->bank.hb.size() * sizeof(C)));                                  \
+        YG_TRY(upload(o->bank.taps.p, o->bank.hb.data(), o->bank.hb.size() * sizeof(C), o->bank.st)); \
+        YG_TRY(o->bank.w.clone_from(q->bank.w, q->bank.st));                                        \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_set_stream(yagi_hip_firinterp_##K q, yagi_stream_t s) {            \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
+        q->bank.st = to_stream(s);                                                                  \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_reset(yagi_hip_firinterp_##K q) {                                  \
+        CHECK_Q(q);                                                                                 \
+        return q->bank.w.reset(q->bank.st);                                                         \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_get_interp_rate(yagi_hip_firinterp_##K q, size_t *interp) {        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(interp);                                                                          \
+        *interp = (size_t)q->interp;                                                                \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_get_sub_len(yagi_hip_firinterp_##K q, size_t *hs) {                \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(hs);                                                                              \
+        *hs = (size_t)q->hs;                                                                        \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_set_scale(yagi_hip_firinterp_##K q, C scale) {                     \
+        CHECK_Q(q);                                                                                 \
+        q->bank.scale = scale;                                                                      \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_get_scale(yagi_hip_firinterp_##K q, C *scale) {                    \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(scale);                                                                           \
+        *scale = q->bank.scale;                                                                     \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_execute(yagi_hip_firinterp_##K q, T x, T *y, size_t ny) {          \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(y);                                                                               \
+        if (ny < (size_t)q->interp) return fail(YAGI_ERR_CONFIG, "output must hold interp samples");\
+        return q->block_host(&x, 1, y);                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_execute_block(yagi_hip_firinterp_##K q, const T *x, size_t nx,     \
+                                               T *y, size_t ny) {                                   \
+        CHECK_Q(q);                                                                                 \
+        if (nx == 0) return YAGI_OK;                                                                \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        if (ny < nx * (size_t)q->interp)                                                            \
+            return fail(YAGI_ERR_CONFIG, "output must hold n*interp samples");                      \
+        return q->block_host(x, nx, y);                                                             \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_execute_block_dev(yagi_hip_firinterp_##K q, const T *x, size_t n,  \
+                                                   T *y) {                                          \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(x, n, y);                                                               \
+    }                                                                                               \
+    int yagi_hip_firinterp_##K##_flush(yagi_hip_firinterp_##K q, T *y, size_t ny) {                 \
+        T zero{};                                                                                   \
+        return yagi_hip_firinterp_##K##_execute(q, zero, y, ny);                                    \
+    }                                                                                               \
+    }
+
+YAGI_FIRINTERP_IMPL(rrrf, RRRF, float, float)
+YAGI_FIRINTERP_IMPL(crcf, CRCF, yagi_cf32, float)
+YAGI_FIRINTERP_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
+
 // ---- FftFilt ---------------------------------------------------------------------------------------
 namespace yagi {
 
