@@ -266,7 +266,8 @@ YAGI_FIRINTERP_API(crcf, yagi_cf32, float)
 YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
 
 /* crcf only: which block kernel execute_block uses.  0 = auto, 1 = general LDS-broadcast kernel
- * (fir_kernels.hip), 2 = register-sliding kernel (stream_kernels.hip).  Test / ablation knob. */
+ * (fir_kernels.hip), 2 = register-sliding kernel, 3 = MFMA Toeplitz kernel (<= 256 taps), 4 = fast
+ * convolution (overlap-save, <= 2049 taps; f32-rounding agreement only) -- all in stream_kernels.hip. */
 int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);
 
 /* ---- Fft<f32>: src/fft/mod.rs:33-69 (arithmetic = rustfft 6.2 in the reference) ------------
@@ -301,7 +302,9 @@ int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q);
 int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s);
 int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale);
 int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q);
-/* variant: 0 = auto, 1 = LDS-broadcast VALU FIR, 2 = MFMA Toeplitz FIR (bench/ablation knob) */
+/* variant: 0 = auto (= 1), 1 = fused, register-sliding VALU FIR, 2 = fused, MFMA Toeplitz FIR (<= 256 taps),
+ * 3 = fast convolution (overlap-save kernel, then batched FFT; <= 2049 taps).  Variant 3 agrees with 1/2 to
+ * f32 rounding but is not exact for integer inputs. */
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant);
 int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes,
                                  yagi_cf32 *spectra);

@@ -145,6 +145,30 @@ def test_firfilt_crcf_mfma_kernel_lengths(ya, oracle, L):
     assert rel_l2(got, truth) <= 2e-6
 
 
+@pytest.mark.parametrize("L", [1, 2, 33, 256, 1000, 2049])
+def test_firfilt_crcf_fast_convolution_kernel(ya, oracle, L):
+    """kernel 4: overlap-save fast convolution (FFT -> product -> IFFT in registers).  Same tolerance as
+    the direct kernels vs the f64 truth; integer exactness is NOT claimed for it."""
+    rng = np.random.default_rng(4000 + L)
+    h, x = rand_taps(rng, "crcf", L), rand_samples(rng, "crcf", 5 * 4096 + 123)
+    q = ya.FirFilter("crcf", h)
+    q.set_kernel(4)
+    q.set_scale(0.75)
+    got = np.concatenate([q.execute_block(x[:7000]), q.execute_block(x[7000:7001]), q.execute_block(x[7001:])])
+    truth = oracle.fir_block_f64("crcf", h, x, scale=0.75)
+    assert np.max(np.abs(got - truth)) <= fir_bound("crcf", h, x)
+    assert rel_l2(got, truth) <= 2e-6
+    q.set_coefficients(h[::-1].copy())            # new taps -> the cached FFT{h} must be rebuilt
+    q.set_scale(0.75)
+    got = q.execute_block(x[:5000])
+    assert rel_l2(got, oracle.fir_block_f64("crcf", h[::-1], x[:5000], scale=0.75)) <= 2e-6
+    if L > 2049 - 1:
+        with pytest.raises(ya.ConfigError):
+            big = ya.FirFilter("crcf", rand_taps(rng, "crcf", 2050))
+            big.set_kernel(4)
+            big.execute_block(x[:4096])
+
+
 def test_config_c1_firfilt_rrrf_63tap_1M(ya, oracle):
     """BASELINE config C1: kaiser(63, 0.2, 60), scale 0.4, 1 048 576 real samples"""
     h = oracle.fir_design_kaiser(63, 0.2, 60.0)
@@ -169,7 +193,7 @@ def test_config_c2_firfilt_crcf_256tap_stream(ya, oracle):
     n = 1 << 20
     x = oracle.gen_complex(SEED + 2, n)
     truth = oracle.fir_block_f64("crcf", h, x, scale=0.4)
-    for choice in (0, 1, 2, 3):
+    for choice in (0, 1, 2, 3, 4):               # 4 = fast convolution (overlap-save, tolerance only)
         q = ya.FirFilter("crcf", h)
         q.set_scale(0.4)
         q.set_kernel(choice)

@@ -26,7 +26,7 @@ def test_stream_small_vs_oracle(ya, oracle, L):
     h = (rng.standard_normal(L) / np.sqrt(L)).astype(np.float32)
     x = oracle.gen_complex(SEED + 2, 12 * 4096)
     truth = spectra_truth(oracle, h, 0.4, x)
-    for variant in ((1, 2) if L <= 256 else (1,)):          # 1 = sliding VALU FIR, 2 = MFMA Toeplitz FIR
+    for variant in ((1, 2, 3) if L <= 256 else (1, 3)):     # 1 sliding VALU FIR, 2 MFMA Toeplitz FIR, 3 fast convolution
         q = ya.FirFftStream(h)
         q.set_scale(0.4)
         q.set_variant(variant)
@@ -65,7 +65,7 @@ def test_stream_integer_alignment_exact(ya):
     x[4096 - 100] = 1.0          # its 256-sample response straddles the frame 0 / frame 1 boundary
     y = np.zeros(3 * 4096)
     y[4096 - 100: 4096 - 100 + 256] = 1.0
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         q = ya.FirFftStream(h)
         q.set_variant(variant)
         got = q.execute(x)
@@ -85,16 +85,26 @@ def test_headline_config_full_block(ya, oracle):
     dy = ya.DeviceArray(n, np.complex64)
     q = ya.FirFftStream(h)
     q.set_scale(0.4)
-    q2 = ya.FirFftStream(h)                 # the other FIR form must give the same spectra
-    q2.set_scale(0.4)
-    q2.set_variant(2)
-    dy_alt = ya.DeviceArray(n, np.complex64)
-    q2.execute_dev(dx, nframes, dy_alt)
     q.execute_dev(dx, nframes, dy)
     ya.synchronize()
-    for f in (5, 3000):
-        assert rel_l2(dy_alt.to_numpy(4096, offset=f * 4096), dy.to_numpy(4096, offset=f * 4096)) <= 2e-6
-    dy_alt.free()
+    # the other FIR forms (MFMA Toeplitz, fast convolution) give the same spectra
+    for variant in (2, 3):
+        q2 = ya.FirFftStream(h)
+        q2.set_scale(0.4)
+        q2.set_variant(variant)
+        dy_alt = ya.DeviceArray(n, np.complex64)
+        q2.execute_dev(dx, nframes, dy_alt)
+        ya.synchronize()
+        for f in (0, 5, 511, 512, 3000, 4095):
+            assert rel_l2(dy_alt.to_numpy(4096, offset=f * 4096), dy.to_numpy(4096, offset=f * 4096)) <= 3e-6, (variant, f)
+        # second call continues the stream (state + chunk offsets)
+        q2.execute_dev(dx, 32, dy_alt)
+        ya.synchronize()
+        tail = dx.to_numpy(255, offset=n - 255)
+        xs = np.concatenate([tail, dx.to_numpy(4096)])
+        truth = np.fft.fft(oracle.fir_block_f64("crcf", h, xs, scale=0.4)[-4096:])
+        assert rel_l2(dy_alt.to_numpy(4096), truth) <= 1e-5, variant
+        dy_alt.free()
     for f in (0, 1, 2047, 4095):
         lo = max(0, f * 4096 - 255)
         xs = dx.to_numpy((f + 1) * 4096 - lo, offset=lo)

@@ -22,13 +22,13 @@ cases = {}
 if "fft" in what:
     plan = ya.Fft(4096, ya.Direction.Forward)
     cases["fft4096 x4096"] = (lambda: plan.run_batch_dev(x, y, n // 4096, st.cuda_stream), 16 * n)
-for name, k in (("fir1", 1), ("fir2", 2), ("fir3", 3)):
+for name, k in (("fir1", 1), ("fir2", 2), ("fir3", 3), ("fir4", 4)):
     if name in what:
         q = ya.FirFilter("crcf", h)
         q.set_kernel(k)
         q.set_stream(st.cuda_stream)
         cases[f"firfilt_crcf256 kernel{k}"] = (lambda q=q: q.execute_block_dev(x, n, y), 16 * n)
-for name, v in (("fused", 1), ("fused2", 2)):
+for name, v in (("fused", 1), ("fused2", 2), ("fused3", 3)):
     if name in what:
         f = ya.FirFftStream(h)
         f.set_stream(st.cuda_stream)

@@ -137,9 +137,12 @@ struct FirFilt {
     DevBuf taps_pad;           // crcf only: zero-padded to Lp floats for the sliding kernel
     DevBuf apack;              // crcf only, L <= 256: Toeplitz A-operand table of the MFMA kernel
     int Lm = 0;                // padded length of the MFMA form (0 = not available)
+    DevBuf hfreq, twf, twb;    // crcf only, L <= 2049: FFT_4096{[h;0]} and both twiddle tables (fast convolution)
+    bool conv_ready = false;
     DevWindow<T> w;
     Workspace ws;
-    int kernel_choice = 0;     // 0 auto, 1 general, 2 sliding (crcf), 3 MFMA Toeplitz (crcf, L <= 256)
+    int kernel_choice = 0;     // 0 auto, 1 general, 2 sliding, 3 MFMA Toeplitz (L <= 256), 4 fast convolution (crcf)
+    int prepare_conv();
 
     int load_taps(const C *hh, size_t n) {
         if (n == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
@@ -148,6 +151,7 @@ struct FirFilt {
         L = (int)n;
         YG_TRY(taps.alloc(n * sizeof(C)));
         YG_TRY(upload(taps.p, h.data(), n * sizeof(C), st));
+        conv_ready = false;
         if (K::id == 1) {
             Lp = (L + 31) / 32 * 32;
             std::vector<float> hp((size_t)Lp, 0.0f);
@@ -182,7 +186,10 @@ template <>
 int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
     YG_TRY(w.flush(st));
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
-    if (kernel_choice == 3 && Lm)
+    if (kernel_choice == 4 && L <= 2049) {
+        YG_TRY(prepare_conv());
+        YG_TRY(launch_fir_crcf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st));
+    } else if (kernel_choice == 3 && Lm)
         YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st));
     else if (slide && Lp <= kSlideMaxTaps)
         YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st));
@@ -311,6 +318,29 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     return YAGI_OK;
 }
 
+// fast-convolution resources of a crcf filter: FFT_4096{[h;0]} computed by the device FFT itself
+template <class K>
+int FirFilt<K>::prepare_conv() {
+    if (conv_ready) return YAGI_OK;
+    if (K::id != 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs crcf and <= 2049 taps");
+    YG_TRY(make_twiddles(4096, YAGI_FFT_FORWARD, twf));
+    YG_TRY(make_twiddles(4096, YAGI_FFT_BACKWARD, twb));
+    std::vector<cf32> hp(4096, cf32{0.f, 0.f});
+    for (int i = 0; i < L; ++i) hp[i] = cf32{reinterpret_cast<const float *>(h.data())[i], 0.f};
+    DevBuf tmp;
+    YG_TRY(tmp.alloc(4096 * sizeof(cf32)));
+    YG_TRY(hfreq.alloc(4096 * sizeof(cf32)));
+    YG_TRY(upload(tmp.p, hp.data(), 4096 * sizeof(cf32), st));
+    FftPlanDev d;
+    d.n = 4096;
+    d.dir = YAGI_FFT_FORWARD;
+    d.tw = twf.as<cf32>();
+    YG_TRY(launch_fft_batch(d, tmp.as<cf32>(), hfreq.as<cf32>(), 1, st));
+    YG_HIP(hipStreamSynchronize(st));
+    conv_ready = true;
+    return YAGI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused firfilt_crcf -> FFT stream
 // ---------------------------------------------------------------------------------------------
@@ -320,6 +350,7 @@ struct FirFft {
     DevBuf tw;
     int variant = 0;
     DevBuf xin, yout;
+    DevBuf scratch;            // variant 3: the FIR output stream between the two kernels
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -822,7 +853,8 @@ YAGI_FIR_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
 // crcf-only knob: which block kernel execute_block uses (0 auto, 1 general, 2 sliding)
 extern "C" int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice) {
     CHECK_Q(q);
-    if (choice < 0 || choice > 3) return fail(YAGI_ERR_CONFIG, "unknown kernel choice %d", choice);
+    if (choice == 4 && q->L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
+    if (choice < 0 || choice > 4) return fail(YAGI_ERR_CONFIG, "unknown kernel choice %d", choice);
     q->kernel_choice = choice;
     return YAGI_OK;
 }
@@ -1273,7 +1305,8 @@ int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) { CHECK_
 int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->fir.w.reset(q->fir.st); }
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     CHECK_Q(q);
-    if (variant < 0 || variant > 2) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    if (variant >= 3 && q->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
     if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
     q->variant = variant;
     return YAGI_OK;
@@ -1285,6 +1318,23 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_PTR(spectra);
     auto &f = q->fir;
     YG_TRY(f.w.flush(f.st));
+    if (q->variant == 3) {
+        // fast-convolution form (two kernels): overlap-save FIR into a scratch stream, then the batched
+        // 4096-point FFT over its frames.  32 B/sample of HBM traffic instead of 16.  (Running the two
+        // kernels as a chunked two-stream pipeline was measured slower: profiles/r01_notes.md.)
+        YG_TRY(f.prepare_conv());
+        const size_t n = nframes * q->nfft;
+        YG_TRY(q->scratch.ensure(n * sizeof(cf32)));
+        FftPlanDev d;
+        d.n = 4096;
+        d.dir = YAGI_FFT_FORWARD;
+        d.tw = q->tw.as<cf32>();
+        cf32 *ys = q->scratch.as<cf32>();
+        YG_TRY(launch_fir_crcf_fftconv(f.w.dev(), x, 0, n, f.hfreq.as<cf32>(), f.scale, f.L, f.twf.as<cf32>(),
+                                       f.twb.as<cf32>(), ys, n, f.st));
+        YG_TRY(launch_fft_batch(d, ys, spectra, nframes, f.st));
+        return f.w.advance(x, n, f.st);
+    }
     YG_TRY(launch_firfft_crcf_4096(f.w.dev(), x, f.taps_pad.as<float>(), f.apack.as<float>(), f.L, f.Lp, f.Lm, f.scale,
                                    q->tw.as<cf32>(), spectra, nframes, q->variant, f.st));
     return f.w.advance(x, nframes * q->nfft, f.st);

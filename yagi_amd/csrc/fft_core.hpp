@@ -56,11 +56,37 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 // position of output k inside v after dft16
 __device__ __forceinline__ constexpr int dft16_pos(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// Twiddles w[c] = W^(c*m), c = 1..15, from FOUR exact table entries (c = 1, 2, 4, 8) and products of
+// at most three of them (depth <= 2 multiplications for 13 of the 15, 3 for w[15]).  A lane needs 15
+// twiddles per pass; fetching each from the table is a 64-address gather per wave instruction and made
+// the L1/TA path -- not HBM, LDS or FP32 -- the bottleneck of the transform.
+__device__ __forceinline__ void twiddle_powers(float2 (&w)[16], const float2 *__restrict__ tw, unsigned m,
+                                               unsigned mask) {
+    w[1] = tw[m & mask];
+    w[2] = tw[(2 * m) & mask];
+    w[4] = tw[(4 * m) & mask];
+    w[8] = tw[(8 * m) & mask];
+    w[3] = cmul(w[2], w[1]);
+    w[5] = cmul(w[4], w[1]);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+    w[9] = cmul(w[8], w[1]);
+    w[10] = cmul(w[8], w[2]);
+    w[11] = cmul(w[8], w[3]);
+    w[12] = cmul(w[8], w[4]);
+    w[13] = cmul(w[8], w[5]);
+    w[14] = cmul(w[8], w[6]);
+    w[15] = cmul(w[8], w[7]);
+}
+
 // Passes 1..3 of the 4096-point transform.  On entry lane b (= threadIdx.x, 0..255) holds
 // v[a] = x[256a + b].  `lds` is a kFft4096LdsFloat2 float2 buffer nobody else touches; `tw` is
 // the W_4096^m table (sign already per direction).  Output goes to out[k], k in [0,4096).
 // Contains 4 __syncthreads(); all 256 lanes must call it.
-template <int SIGN, bool GUARD = false>
+// TWP = twiddles by powers (4 exact loads + products) -- right for the HBM-bound kernels; the fused
+// direct-form kernels are FP32-issue bound instead and keep the 15 table gathers per pass (TWP = false),
+// which cost no VALU work.
+template <int SIGN, bool GUARD = false, bool TWP = true>
 __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restrict__ lds,
                                                const float2 *__restrict__ tw,
                                                float2 *__restrict__ out) {
@@ -70,10 +96,12 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
     // ---- pass 1 (lane b = t) ----
     if (active) {
         dft16<SIGN>(v);
+        float2 w[16];
+        if (TWP) twiddle_powers(w, tw, t, 4095u);  // W4096^(t*c): t*c < 4096, the mask never wraps
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float2 z = v[dft16_pos(c)];
-            if (c) z = cmul(z, tw[(unsigned)(t * c)]);
+            if (c) z = cmul(z, TWP ? w[c] : tw[(unsigned)(t * c)]);
             lds[c * kEx1Stride + t] = z;
         }
     }
@@ -88,10 +116,12 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
         __syncthreads();                       // exchange-1 reads done before the buffer is reused
         if (active) {
             dft16<SIGN>(v);
+            float2 w[16];
+            if (TWP) twiddle_powers(w, tw, 16 * bp, 4095u);   // W256^(b'*c') = W4096^(16 b' c') < 3600
 #pragma unroll
             for (int cp = 0; cp < 16; ++cp) {
                 float2 u = v[dft16_pos(cp)];
-                if (cp) u = cmul(u, tw[(unsigned)(16 * bp * cp)]);
+                if (cp) u = cmul(u, TWP ? w[cp] : tw[(unsigned)(16 * bp * cp)]);
                 lds[bp * kEx2Stride + cp * 16 + c] = u;
             }
         }
@@ -106,6 +136,50 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
         for (int d = 0; d < 16; ++d) out[t + 256 * d] = v[dft16_pos(d)];
     }
     __syncthreads();                           // LDS free for the caller's next transform
+}
+
+// Same three passes, but the result stays in registers: on return lane t holds X[t + 256 d] in v[d]
+// (d = 0..15) -- which is exactly the layout pass 1 expects, so transforms can be chained
+// (FFT -> pointwise product -> inverse FFT) without touching LDS or HBM in between.
+template <int SIGN>
+__device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
+                                                       const float2 *__restrict__ tw) {
+    const unsigned t = threadIdx.x;
+    dft16<SIGN>(v);
+    {
+        float2 w[16];
+        twiddle_powers(w, tw, t, 4095u);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul(z, w[c]);
+            lds[c * kEx1Stride + t] = z;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned c = t >> 4, bp = t & 15;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = lds[c * kEx1Stride + 16 * a + bp];
+        __syncthreads();
+        dft16<SIGN>(v);
+        float2 wt[16];
+        twiddle_powers(wt, tw, 16 * bp, 4095u);
+#pragma unroll
+        for (int cp = 0; cp < 16; ++cp) {
+            float2 u = v[dft16_pos(cp)];
+            if (cp) u = cmul(u, wt[cp]);
+            lds[bp * kEx2Stride + cp * 16 + c] = u;
+        }
+    }
+    __syncthreads();
+    float2 w[16];
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) w[bp] = lds[bp * kEx2Stride + t];
+    dft16<SIGN>(w);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) v[d] = w[dft16_pos(d)];
+    __syncthreads();
 }
 
 }  // namespace yagi

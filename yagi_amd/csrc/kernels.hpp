@@ -60,6 +60,13 @@ void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack_host);
 int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lm, float scale,
                          cf32 *y, size_t ny, hipStream_t st);
 
+// Fast convolution (overlap-save, 4096-pt blocks) form of firfilt_crcf: hs = FFT_4096{[h;0]} (unscaled),
+// forward table twf, backward table twb; 1 <= L <= 2049.
+// x[-pre .. x_avail) must be readable (chunked processing of one long block); ny outputs are produced.
+int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
+                            float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
+                            hipStream_t st);
+
 // ---- fft_kernels.hip -----------------------------------------------------------------------
 struct FftPlanDev {
     int n = 0;

@@ -162,7 +162,7 @@ firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__re
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = fl[padded(256 * a + threadIdx.x)];
         __syncthreads();
-        fft4096_passes<-1>(v, fl, tw, spectra + f * kTile);
+        fft4096_passes<-1, false, false>(v, fl, tw, spectra + f * kTile);
     }
 }
 
@@ -294,7 +294,7 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
                 for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
             }
             __syncthreads();
-            fft4096_passes<-1, (NW > 4)>(v, xs, tw, out + o0);
+            fft4096_passes<-1, (NW > 4), false>(v, xs, tw, out + o0);
         } else {
             const int nt = (int)((n_units - o0) < (size_t)kTile ? (n_units - o0) : (size_t)kTile);
 #ifndef YG_ABL_NOSTORE
@@ -352,6 +352,80 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
                          cf32 *y, size_t ny, hipStream_t st) {
     if (ny == 0) return YAGI_OK;
     return launch_mfma<false>(win, x, apack, L, Lp, scale, nullptr, y, ny, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast convolution (overlap-save) form of firfilt_crcf: the reference's own fast-convolution object is
+// FftFilt (src/filter/fftfilt.rs:103-138, overlap-add); this is the overlap-save arrangement of the
+// same identity, one 4096-point block per workgroup:
+//   block b reads X[V*b - (L-1) .. V*b + V) (4096 samples, V = 4096 - (L-1) valid outputs),
+//   FFT (3 register passes) -> the spectrum stays in registers in exactly the lane layout the next
+//   transform's first pass wants (lane t holds bins t + 256d) -> multiply by FFT{h} * scale/4096 ->
+//   inverse FFT -> the last V time samples are y[V*b .. V*b + V).
+// 2 x 245 760 flop per 4096-V.. block instead of 4*L flop per sample: ~134 flop/sample at L = 256, so the
+// kernel is bound by HBM/LDS, not FP32.  Traffic: 8*(4096/V) B read + 8 B written per sample.
+// Results agree with the direct form to f32 rounding (rel 1e-6) but are NOT exact for integer inputs,
+// so this is an opt-in kernel choice, not FirFilter's default.
+// ---------------------------------------------------------------------------------------------
+// x[-pre .. x_avail) is readable (pre = samples of the same stream stored in front of x[0], used when a
+// long block is processed in chunks); older samples come from `win` (the L-sample filter window).
+__global__ void __launch_bounds__(256)
+firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x, long long pre,
+                            long long x_avail, const float2 *__restrict__ hs, float sc, int L, int V,
+                            const float2 *__restrict__ twf, const float2 *__restrict__ twb,
+                            float2 *__restrict__ y, size_t ny) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const size_t nblk = (ny + V - 1) / V;
+    for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const long long base = (long long)b * V - (L - 1);
+        float2 v[16];
+        if (base >= -pre && base + 4096 <= x_avail) {
+            const float2 *src = x + base;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = src[256 * a + threadIdx.x];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const long long idx = base + 256 * a + threadIdx.x;
+                float2 s = make_float2(0.f, 0.f);
+                if (idx >= -pre) { if (idx < x_avail) s = x[idx]; }
+                else if (idx >= -(long long)L) s = win[L + idx];
+                v[a] = s;
+            }
+        }
+        // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
+        fft4096_passes_to_regs<-1>(v, lds, twf);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const float2 p = cmul(v[d], hs[threadIdx.x + 256 * d]);
+            v[d] = make_float2(p.x * sc, p.y * sc);
+        }
+        fft4096_passes_to_regs<+1>(v, lds, twb);
+        // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
+        const size_t o0 = b * (size_t)V;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const int n = (int)threadIdx.x + 256 * d - (L - 1);
+            if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
+        }
+    }
+}
+
+int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
+                            float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
+                            hipStream_t st) {
+    if (ny == 0) return YAGI_OK;
+    if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
+    const int V = 4096 - (L - 1);
+    const size_t nblk = (ny + V - 1) / V;
+    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
+    firfilt_crcf_fftconv_kernel<<<grid, 256, 0, st>>>(
+        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), (long long)pre,
+        (long long)x_avail, reinterpret_cast<const float2 *>(hs), scale / 4096.0f, L, V,
+        reinterpret_cast<const float2 *>(twf), reinterpret_cast<const float2 *>(twb),
+        reinterpret_cast<float2 *>(y), ny);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
 }
 
 // M = 1 crcf block FIR with the sliding kernel; taps_pad = h zero-padded to Lp = roundup(L, 32)
