@@ -10,7 +10,8 @@ import torch
 
 import yagi_amd as ya
 
-what = sys.argv[1:] or ["fft", "fir2", "fused"]
+SUSTAIN = "--sustain" in sys.argv          # steady-state (DVFS-settled) timing: 300 launches, last 100 timed
+what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fft", "fir2", "fused"]
 n = 1 << 24
 dev = torch.device("cuda")
 x = torch.empty(n, dtype=torch.complex64, device=dev)
@@ -59,6 +60,20 @@ else:
 for fn, _ in cases.values():
     fn()
 torch.cuda.synchronize()
+if SUSTAIN:
+    for k, (fn, nbytes) in cases.items():
+        for _ in range(200):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(100):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 100
+        nn = BIG.get(k, n)
+        print(f"{k:28s} sustained {ms:8.4f} ms  {nn / ms / 1e6:9.1f} Gsamples/s  {nbytes / ms / 1e6:8.1f} GB/s algorithmic")
+    sys.exit(0)
 res = {k: [] for k in cases}
 for rnd in range(5):
     for k, (fn, _) in cases.items():
