@@ -32,6 +32,19 @@ def test_firpfbch_vs_oracle(ya, oracle, M, m):
     assert rel_l2(q.analyzer_execute(x[: 5 * M]), want[:5]) <= 2e-6
 
 
+@pytest.mark.parametrize("M,m,nfr", [(64, 8, 4099), (64, 2, 1000), (128, 4, 777), (256, 8, 300), (256, 2, 64), (64, 4, 65)])
+def test_firpfbch_column_kernel_long_runs(ya, oracle, M, m, nfr):
+    """the column-sliding kernel (M in {64,128,256}, p in {4,8,16}): ragged frame counts, carried state"""
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+    x = oracle.gen_complex(SEED + 4, nfr * M)
+    want = oracle.FirPfbCh(M, 2 * m, h).analyzer_execute(x)
+    q = ya.FirPfbCh(M, 2 * m, h)
+    k = (nfr * 2) // 3
+    got = np.concatenate([q.analyzer_execute(x[: k * M]), q.analyzer_execute(x[k * M:])])
+    assert rel_l2(got, want) <= 2e-6
+    assert np.max(np.abs(got - want)) <= 2e-5 * float(np.max(np.abs(want)))
+
+
 def test_firpfbch_kaiser_ctor_and_tone(ya, oracle):
     M, m = 64, 8
     q = ya.FirPfbCh.new_kaiser(M, m, 60.0)

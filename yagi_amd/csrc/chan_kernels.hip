@@ -136,6 +136,114 @@ firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// firpfbch, column-sliding form (M in {64,128,256}, p in {4,8,16}): every lane owns ONE branch column c
+// and walks a run of consecutive frames with its p taps and the last p samples of that column in
+// registers (one coalesced 8-byte load + p packed FMAs per frame and lane, no LDS in the FIR part).
+// A workgroup = 256/M column groups, each on its own run of frames; per tile of 16 frames the branch
+// outputs go to LDS once, the workgroup runs the M-point register-butterfly passes over all 256/M*16
+// transforms together and stores [frame][channel] fully coalesced.
+// HBM traffic: 8 B/sample in (+ (p-1)/run halo, L2-served between the groups of one workgroup) + 8 out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kColTile = 16;
+constexpr int kColHalf = 8;
+#ifndef YG_COL_WGS
+#define YG_COL_WGS 1024
+#endif
+
+template <int P>
+__global__ void __launch_bounds__(256)
+firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                    const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
+                    float2 *__restrict__ y, size_t nframes, int run) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 frames][M]
+    float2 *vb = va + 256 * kColHalf;
+    float2 *twl = vb + 256 * kColHalf;                          // M
+    const int G = 256 / M;
+    const int lgM = 31 - __builtin_clz((unsigned)M);
+    const int g = threadIdx.x >> lgM, c = threadIdx.x & (M - 1);
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    float hc[P];
+#pragma unroll
+    for (int n = 0; n < P; ++n) hc[n] = h[(M - 1 - c) + n * M];
+    const int hist_len = (P - 1) * M;
+    const long long x_len = (long long)nframes * M;
+    const size_t ngroups = (nframes + run - 1) / run;
+    for (size_t gblk = blockIdx.x; gblk * G < ngroups; gblk += gridDim.x) {
+        const long long f_begin = (long long)(gblk * G + g) * run;       // may lie past the end: all guarded
+        float2 w[P];                                                     // ring: frame f at slot (f - f_begin) mod P
+#pragma unroll
+        for (int n = 1; n < P; ++n)
+            w[P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + c, x_len);
+        for (int t0 = 0; t0 < run; t0 += kColTile) {
+            float2 xin[kColTile];
+#pragma unroll
+            for (int j = 0; j < kColTile; ++j) {
+                const long long f = f_begin + t0 + j;
+                xin[j] = (f < (long long)nframes) ? x[f * M + c] : make_float2(0.f, 0.f);
+            }
+            float2 acc[kColTile];
+#pragma unroll
+            for (int j = 0; j < kColTile; ++j) {
+                w[j % P] = xin[j];
+                acc[j] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < P; ++n) {
+                    const float2 sv = w[(j - n + 4 * P) % P];
+                    acc[j].x = fmaf(sv.x, hc[n], acc[j].x);
+                    acc[j].y = fmaf(sv.y, hc[n], acc[j].y);
+                }
+            }
+            // the 16 frames go through the M-point transforms in two halves of 8 so the two LDS buffers
+            // stay at 16 KiB each (4 workgroups per CU)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * M + c] = acc[half * kColHalf + j];
+                __syncthreads();
+                float2 *res = lds_fft_pow2<-1>(va, vb, M, G * kColHalf, plan, twl, 1);
+                // transform q = g'*8 + j is frame f_begin(g') + t0 + 8*half + j
+                for (int e = threadIdx.x; e < 256 * kColHalf; e += 256) {
+                    const int q = e >> lgM, k = e & (M - 1);
+                    const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
+                    const long long f = (long long)(gblk * G + gq) * run + t0 + j;
+                    if (t0 + j < run && f < (long long)nframes) y[f * M + k] = res[e];
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int P>
+static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, int M, const cf32 *twM,
+                               cf32 *y, size_t nframes, hipStream_t st) {
+    const int G = 256 / M;
+    // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
+    // >= ~2048 workgroups
+    size_t run = nframes / ((size_t)YG_COL_WGS * G);
+    run = run / kColTile * kColTile;
+    if (run < (size_t)kColTile) run = kColTile;
+    if (run > 256) run = 256;
+    const size_t ngroups = (nframes + run - 1) / run;
+    const size_t nblk = (ngroups + G - 1) / G;
+    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
+    const size_t lds = (2 * 256 * (size_t)kColHalf + (size_t)M) * sizeof(float2);
+    static bool raised = false;
+    if (!raised) {
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    firpfbch_col_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
+                                                  reinterpret_cast<const float2 *>(x), h, M,
+                                                  reinterpret_cast<const float2 *>(twM), make_pow2_plan(M),
+                                                  reinterpret_cast<float2 *>(y), nframes, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 static constexpr size_t kChanLdsBudget = 38 * 1024;   // <= 4 workgroups per CU
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -143,6 +251,14 @@ static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
                     const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
+    if ((M == 64 || M == 128 || M == 256) && nframes >= 64) {
+        switch (p) {
+            case 4: return launch_firpfbch_col<4>(hist, x, h, M, twM, y, nframes, st);
+            case 8: return launch_firpfbch_col<8>(hist, x, h, M, twM, y, nframes, st);
+            case 16: return launch_firpfbch_col<16>(hist, x, h, M, twM, y, nframes, st);
+            default: break;
+        }
+    }
     // frames per tile: as many as fit the LDS budget (>= 1)
     int F = 4096 / M;
     if (F < 1) F = 1;

@@ -54,10 +54,11 @@ __device__ __forceinline__ void stockham_pass(const float2 *__restrict__ src, fl
                                               int N, int Ns, int nfr, const float2 *__restrict__ twl,
                                               int tw_scale, bool tw_is_forward = true) {
     const int T = N / R;
+    const int lgT = 31 - __builtin_clz((unsigned)T);       // N, R powers of two: index math by shifts
     const int total = T * nfr;
     const int tw_k = (N / (Ns * R)) * tw_scale;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int fr = e / T, j = e - fr * T;
+        const int fr = e >> lgT, j = e & (T - 1);
         const int k = j & (Ns - 1);
         const float2 *s = src + fr * N + j;
         float2 v[R];
