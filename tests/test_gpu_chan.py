@@ -89,6 +89,29 @@ def test_firpfbch2_vs_oracle(ya, oracle, M, m):
     assert rel_l2(q.analyzer_execute(x[: 9 * M2]), want[:9]) <= 2e-6
 
 
+@pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200)])
+def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
+    """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8}, even first step) incl. ragged tails"""
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
+    h = (h * M / h.sum()).astype(np.float32)
+    M2 = M // 2
+    x = oracle.gen_complex(SEED + 5, ns * M2)
+    want = oracle.FirPfbCh2(M, m, h).analyzer_execute(x)
+    q = ya.FirPfbCh2(M, m, h)
+    k = ((ns * 2) // 3) & ~1                      # even split keeps the second call on the fast path
+    got = np.concatenate([q.analyzer_execute(x[: k * M2]), q.analyzer_execute(x[k * M2:])])
+    assert rel_l2(got, want) <= 2e-6
+    # sharded form on the same kernel
+    for R in (2, 8):
+        dx = ya.DeviceArray.from_numpy(x)
+        for r in (0, R - 1):
+            qs = ya.FirPfbCh2(M, m, h)
+            shard = ya.DeviceArray(ns * (M // R), np.complex64)
+            qs.analyzer_execute_shard_dev(dx, ns, r, R, shard)
+            ya.synchronize()
+            assert rel_l2(shard.to_numpy().reshape(ns, M // R), want[:, r::R]) <= 3e-6, (R, r)
+
+
 def test_firpfbch2_kaiser_tone_unit_gain(ya):
     M, m = 256, 4
     q = ya.FirPfbCh2.new_kaiser(M, m, 60.0)

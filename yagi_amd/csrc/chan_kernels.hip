@@ -370,6 +370,137 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// firpfbch2, column-sliding form (M in {64,128,256}, branch length P = 2m in {2,4,8}, even first step):
+// lane b owns window b.  A window is fed once per PAIR of steps (even steps feed b < M/2, odd steps feed
+// b >= M/2) and produces an output on both steps of the pair with two different tap sets
+// (i = b on even steps, i = b - M/2 mod M on odd steps).  Per pair and lane: one coalesced 8-byte load and
+// 2*P packed FMAs out of registers.  To keep the code free of divergence the even-step taps of the lanes
+// with b >= M/2 (which must see the window BEFORE this pair's sample) are stored rotated by one slot.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ void __launch_bounds__(256)
+firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
+                     const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
+                     int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, even */) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][M]
+    float2 *vb = va + 256 * kColHalf;
+    float2 *twl = vb + 256 * kColHalf;                          // M
+    const int G = 256 / M, M2 = M / 2, Mr = M / R;
+    const int lgM = 31 - __builtin_clz((unsigned)M), lgMr = 31 - __builtin_clz((unsigned)Mr);
+    const int g = threadIdx.x >> lgM, b = threadIdx.x & (M - 1);
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    const int bpar = (b >= M2) ? 1 : 0;
+    const int pos = bpar ? (M - 1 - b) : (M2 - 1 - b);
+    const int i1 = (b - M2 + M) & (M - 1);
+    float h0r[P], h1[P];                                         // h0r[m] pairs with ring slot (kk - m)
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+        const int n0 = bpar ? (m + P - 1) % P : m;              // rotated for the late-fed half
+        h0r[m] = h[b + n0 * M];
+        h1[m] = h[i1 + m * M];
+    }
+    const float invM = 1.0f / (float)M;
+    const long long x_len = (long long)nsteps * M2;
+    const size_t ngroups = (nsteps + run - 1) / run;
+    for (size_t gblk = blockIdx.x; gblk * G < ngroups; gblk += gridDim.x) {
+        const long long s_begin = (long long)(gblk * G + g) * run;       // even
+        // sample of local pair kk: X[(s_begin + 2kk + bpar)*M2 + pos], kept in ring slot kk mod P
+        float2 w[P];
+#pragma unroll
+        for (int n = 1; n <= P; ++n)                                     // pairs -1 .. -P
+            w[(P - n) % P] = load_hist(hist, hist_len, x, (s_begin - 2 * n + bpar) * M2 + pos, x_len);
+        for (int t0 = 0; t0 < run; t0 += kColTile) {
+            float2 xin[kColHalf];
+#pragma unroll
+            for (int kk = 0; kk < kColHalf; ++kk) {
+                const long long sx = s_begin + t0 + 2 * kk + bpar;
+                xin[kk] = (sx < (long long)nsteps) ? x[sx * M2 + pos] : make_float2(0.f, 0.f);
+            }
+            float2 acc[kColTile];
+#pragma unroll
+            for (int kk = 0; kk < kColHalf; ++kk) {
+                const float2 old = w[kk % P];
+                // even step: the early-fed half already sees the new sample, the late-fed half the old one
+                w[kk % P] = bpar ? old : xin[kk];
+                float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const float2 sv = w[(kk - m + 4 * P) % P];
+                    a0.x = fmaf(sv.x, h0r[m], a0.x);
+                    a0.y = fmaf(sv.y, h0r[m], a0.y);
+                }
+                w[kk % P] = xin[kk];                                      // odd step: everybody is fed
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const float2 sv = w[(kk - m + 4 * P) % P];
+                    a1.x = fmaf(sv.x, h1[m], a1.x);
+                    a1.y = fmaf(sv.y, h1[m], a1.y);
+                }
+                acc[2 * kk] = a0;
+                acc[2 * kk + 1] = a1;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * M + b] = acc[half * kColHalf + j];
+                __syncthreads();
+                float2 *srcb = va, *dstb = vb;
+                const int nq = G * kColHalf;                               // transforms in flight
+                if (R > 1) {
+                    for (int e = threadIdx.x; e < nq * Mr; e += 256) {
+                        const int q = e >> lgMr, bq = e & (Mr - 1);
+                        float2 a = make_float2(0.f, 0.f);
+                        for (int aa = 0; aa < R; ++aa) {
+                            float2 wv = twl[((aa * rank) % R) * Mr];
+                            wv.y = -wv.y;
+                            a = cadd(a, cmul(va[q * M + Mr * aa + bq], wv));
+                        }
+                        float2 w2 = twl[(bq * rank) & (M - 1)];
+                        w2.y = -w2.y;
+                        vb[e] = cmul(a, w2);
+                    }
+                    __syncthreads();
+                    srcb = vb;
+                    dstb = va;
+                }
+                float2 *res = lds_fft_pow2<+1>(srcb, dstb, Mr, nq, plan, twl, R);
+                for (int e = threadIdx.x; e < nq * Mr; e += 256) {
+                    const int q = e >> lgMr, k = e & (Mr - 1);
+                    const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
+                    const long long sg = (long long)(gblk * G + gq) * run + t0 + j;
+                    if (t0 + j < run && sg < (long long)nsteps) {
+                        const float2 v = res[e];
+                        y[sg * Mr + k] = make_float2(v.x * invM, v.y * invM);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int P>
+static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M,
+                                const cf32 *twM, int rank, int nranks, cf32 *y, size_t nsteps, hipStream_t st) {
+    const int G = 256 / M;
+    size_t run = nsteps / ((size_t)YG_COL_WGS * G);
+    run = run / kColTile * kColTile;
+    if (run < (size_t)kColTile) run = kColTile;
+    if (run > 512) run = 512;
+    const size_t ngroups = (nsteps + run - 1) / run;
+    const size_t nblk = (ngroups + G - 1) / G;
+    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
+    const size_t lds = (2 * 256 * (size_t)kColHalf + (size_t)M) * sizeof(float2);
+    firpfbch2_col_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist), hist_len,
+                                                   reinterpret_cast<const float2 *>(x), h, M,
+                                                   reinterpret_cast<const float2 *>(twM), make_pow2_plan(M / nranks),
+                                                   rank, nranks, reinterpret_cast<float2 *>(y), nsteps, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
                      const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
                      hipStream_t st) {
@@ -379,6 +510,14 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
         return fail(YAGI_ERR_CONFIG, "firpfbch2: %d channels do not shard over %d ranks", M, nranks);
     const size_t lead = (size_t)(p - 1) * M + M2;
     if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
+    if ((M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 && is_pow2(M / nranks)) {
+        switch (p) {
+            case 2: return launch_firpfbch2_col<2>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
+            case 4: return launch_firpfbch2_col<4>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
+            case 8: return launch_firpfbch2_col<8>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
+            default: break;
+        }
+    }
     int S = 4096 / M;
     if (S < 1) S = 1;
     const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
