@@ -292,6 +292,57 @@ int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n);
 int yagi_hip_fft_shift_dev(yagi_cf32 *buf_dev, size_t n, size_t batch, yagi_stream_t s);
 int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n, int direction);
 
+/* ---- Spgram<T>: src/fft/spgram.rs (Welch spectral periodogram; the in-tree consumer of window -> FFT) ----
+ *   spgramcf = Spgram<Complex32>, spgramf = Spgram<f32>.
+ *   create          new(nfft, wtype, window_len, delay)   :49-125  (nfft < 2, window_len > nfft, window_len == 0,
+ *                                                                   delay == 0, Kaiser with odd window_len -> CONFIG;
+ *                                                                   additionally nfft <= 8192 in this engine)
+ *   create_default  default(nfft) = new(nfft, Kaiser, nfft/2, nfft/4)   :128-131
+ *   clear / reset                                          :135-155
+ *   set_alpha / get_alpha   (-1 = accumulate, else [0,1])  :158-174,229
+ *   set_freq / set_rate / get_nfft / get_window_len / get_delay / get_wtype / counters   :177-226
+ *   push / write    one transform every `delay` samples    :237-259  (write = the batched device form)
+ *   get_psd_mag / get_psd   fft-shifted linear / dB        :292-316  (like the reference, the linear scale
+ *                                                                   factor is 0 unless alpha == -1)
+ *   estimate_psd    one-shot                               :319-330
+ * wtype uses the reference's WindowType discriminants (math/windows.rs:7-18). */
+#define YAGI_WINDOW_HAMMING 1
+#define YAGI_WINDOW_HANN 2
+#define YAGI_WINDOW_BLACKMANHARRIS 3
+#define YAGI_WINDOW_BLACKMANHARRIS7 4
+#define YAGI_WINDOW_KAISER 5
+#define YAGI_WINDOW_FLATTOP 6
+#define YAGI_WINDOW_TRIANGULAR 7
+#define YAGI_WINDOW_RCOSTAPER 8
+#define YAGI_WINDOW_KBD 9
+#define YAGI_SPGRAM_API(K, T)                                                                       \
+    typedef struct yagi_hip_spgram##K##_s *yagi_hip_spgram##K;                                      \
+    int yagi_hip_spgram##K##_create(size_t nfft, int wtype, size_t window_len, size_t delay,        \
+                                    yagi_hip_spgram##K *q);                                         \
+    int yagi_hip_spgram##K##_create_default(size_t nfft, yagi_hip_spgram##K *q);                    \
+    int yagi_hip_spgram##K##_destroy(yagi_hip_spgram##K q);                                         \
+    int yagi_hip_spgram##K##_set_stream(yagi_hip_spgram##K q, yagi_stream_t s);                     \
+    int yagi_hip_spgram##K##_clear(yagi_hip_spgram##K q);                                           \
+    int yagi_hip_spgram##K##_reset(yagi_hip_spgram##K q);                                           \
+    int yagi_hip_spgram##K##_set_alpha(yagi_hip_spgram##K q, float alpha);                          \
+    int yagi_hip_spgram##K##_get_alpha(yagi_hip_spgram##K q, float *alpha);                         \
+    int yagi_hip_spgram##K##_set_freq(yagi_hip_spgram##K q, float freq);                            \
+    int yagi_hip_spgram##K##_set_rate(yagi_hip_spgram##K q, float rate);                            \
+    int yagi_hip_spgram##K##_get_params(yagi_hip_spgram##K q, size_t *nfft, size_t *window_len,     \
+                                        size_t *delay, int *wtype);                                 \
+    int yagi_hip_spgram##K##_get_counters(yagi_hip_spgram##K q, uint64_t *num_samples,              \
+                                          uint64_t *num_samples_total, uint64_t *num_transforms,    \
+                                          uint64_t *num_transforms_total);                          \
+    int yagi_hip_spgram##K##_push(yagi_hip_spgram##K q, T x);                                       \
+    int yagi_hip_spgram##K##_write(yagi_hip_spgram##K q, const T *x, size_t n);                     \
+    int yagi_hip_spgram##K##_write_dev(yagi_hip_spgram##K q, const T *x_dev, size_t n);             \
+    int yagi_hip_spgram##K##_get_psd_mag(yagi_hip_spgram##K q, float *psd, size_t n);               \
+    int yagi_hip_spgram##K##_get_psd(yagi_hip_spgram##K q, float *psd, size_t n);                   \
+    int yagi_hip_spgram##K##_estimate_psd(size_t nfft, const T *x, size_t n, float *psd);
+
+YAGI_SPGRAM_API(cf, yagi_cf32)
+YAGI_SPGRAM_API(f, float)
+
 /* ---- the headline stream: FirFilter<Complex32,f32>::execute_block
  * (firfilt.rs:267-278) feeding consecutive nfft-sample frames to Fft::run forward
  * (fft/mod.rs:45-48), fused so the FIR output never touches HBM.  nfft = 4096 (fused kernel);

@@ -121,6 +121,8 @@ def lib():
         L.yo_firpfbch2_destroy.argtypes = [vp]
         L.yo_firpfbch2_analyzer_execute.argtypes = [vp, vp, sz, vp]
         L.yo_stream_fir_fft.argtypes = [vp, vp, vp, sz, vp, vp]
+        L.yo_window_fn.restype = fp
+        L.yo_window_fn.argtypes = [C.c_int, sz, sz, fp]
         L.yo_fftfilt_create.restype = vp
         L.yo_fftfilt_create.argtypes = [C.c_int, vp, sz, sz]
         L.yo_fftfilt_destroy.argtypes = [vp]
@@ -531,6 +533,103 @@ class FftFilt:
         y = np.empty_like(x)
         self.L.yo_fftfilt_execute(self.h, _p(x), _p(y))
         return y
+
+
+def window_fn(wtype, i, wlen, arg=0.0):
+    return np.float32(lib().yo_window_fn(int(wtype), i, wlen, arg))
+
+
+class Spgram:
+    """Restatement of fft::Spgram<T> (spgram.rs:49-330).  The FFT is numpy's f64 transform rounded to
+    f32 (the reference's is rustfft f32); everything else follows the reference statement by statement,
+    including the 0.0 linear scale when alpha != -1 (spgram.rs:295-299)."""
+    PSD_MIN = np.float32(1e-12)
+
+    def __init__(self, nfft, wtype, window_len, delay, dtype=np.complex64):
+        if nfft < 2 or window_len > nfft or window_len == 0 or delay == 0:
+            raise ValueError("config")
+        if int(wtype) == 5 and window_len % 2:
+            raise ValueError("config")
+        if not 1 <= int(wtype) <= 9:
+            raise ValueError("config")
+        self.nfft, self.wtype, self.window_len, self.delay = nfft, int(wtype), window_len, delay
+        self.dtype = np.dtype(dtype)
+        self.buffer = Window(window_len, self.dtype)
+        arg = {5: 10.0, 9: 3.0, 7: float(window_len), 8: float(window_len // 3)}.get(self.wtype, 0.0)
+        w = np.array([window_fn(self.wtype, i, window_len, arg) for i in range(window_len)], np.float32)
+        if np.any(np.isnan(w)):
+            raise ValueError("value")
+        g = np.float32(0)
+        for v in w:
+            g = np.float32(g + v * v)
+        self.w = (np.float32(1.0) / np.sqrt(g)) * w
+        self.set_alpha(-1.0)
+        self.reset()
+
+    @classmethod
+    def default(cls, nfft, dtype=np.complex64):
+        if nfft < 2:
+            raise ValueError("config")
+        return cls(nfft, 5, nfft // 2, nfft // 4, dtype)
+
+    def clear(self):
+        self.sample_timer = self.delay
+        self.num_transforms = 0
+        self.num_samples = 0
+        self.psd = np.zeros(self.nfft, np.float32)
+
+    def reset(self):
+        self.clear()
+        self.buffer.reset()
+        self.num_samples_total = 0
+        self.num_transforms_total = 0
+
+    def set_alpha(self, a):
+        if a != -1.0 and not 0.0 <= a <= 1.0:
+            raise ValueError("config")
+        self.accumulate = a == -1.0
+        self.alpha = np.float32(1.0 if self.accumulate else a)
+        self.gamma = np.float32(1.0 if self.accumulate else 1.0 - np.float32(a))
+
+    def push(self, x):
+        self.buffer.push(x)
+        self.num_samples += 1
+        self.num_samples_total += 1
+        self.sample_timer -= 1
+        if self.sample_timer == 0:
+            self.sample_timer = self.delay
+            self.step()
+
+    def write(self, xs):
+        for v in xs:
+            self.push(v)
+
+    def step(self):
+        rc = self.buffer.read()
+        t = np.zeros(self.nfft, np.complex64)
+        t[: self.window_len] = (rc * self.w).astype(np.complex64)
+        f = np.fft.fft(t.astype(np.complex128)).astype(np.complex64)
+        mag = (f.real * f.real + f.imag * f.imag).astype(np.float32)
+        self.psd = mag if self.num_transforms == 0 else (self.gamma * self.psd + self.alpha * mag).astype(np.float32)
+        self.num_transforms += 1
+        self.num_transforms_total += 1
+
+    def get_psd_mag(self):
+        scale = np.float32(1.0 / max(1, self.num_transforms)) if self.accumulate else np.float32(0.0)
+        k = (np.arange(self.nfft) + self.nfft // 2) % self.nfft
+        return (np.maximum(self.psd[k], self.PSD_MIN) * scale).astype(np.float32)
+
+    def get_psd(self):
+        with np.errstate(divide="ignore"):
+            return (10.0 * np.log10(self.get_psd_mag())).astype(np.float32)
+
+    @classmethod
+    def estimate_psd(cls, nfft, x, dtype=np.complex64):
+        q = cls.default(nfft, dtype)
+        q.write(x)
+        if q.num_transforms == 0:
+            q.step()
+        return q.get_psd()
 
 
 def stream_fir_fft(h, scale, x, nfft):

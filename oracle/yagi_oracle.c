@@ -492,6 +492,49 @@ int yo_fir_design_kaiser(size_t n, float fc, float as_, float mu, float *h) {
 }
 
 /* ------------------------------------------------------------------------------------
+ * taper windows, src/math/windows.rs:76-205 (f32).  type = WindowType discriminant:
+ * 1 Hamming 2 Hann 3 BlackmanHarris 4 BlackmanHarris7 5 Kaiser 6 FlatTop 7 Triangular
+ * 8 RcosTaper 9 Kbd.  Returns NaN where the reference returns Err.
+ * ---------------------------------------------------------------------------------- */
+float yo_window_fn(int type, size_t i, size_t wlen, float arg) {
+    const float t = 2.0f * PI_F * (float)i / (float)(wlen - 1);
+    switch (type) {
+    case 1: return 0.53836f - 0.46164f * cosf((2.0f * PI_F * (float)i) / (float)(wlen - 1));
+    case 2: return 0.5f - 0.5f * cosf((2.0f * PI_F * (float)i) / (float)(wlen - 1));
+    case 3: return 0.35875f - 0.48829f * cosf(t) + 0.14128f * cosf(2.0f * t) - 0.01168f * cosf(3.0f * t);
+    case 4: return 0.27105f - 0.43329f * cosf(t) + 0.21812f * cosf(2.0f * t) - 0.06592f * cosf(3.0f * t)
+                 + 0.01081f * cosf(4.0f * t) - 0.00077f * cosf(5.0f * t) + 0.00001f * cosf(6.0f * t);
+    case 5: return (i >= wlen || arg < 0.0f) ? NAN : yo_window_kaiser(i, wlen, arg);
+    case 6: return 1.000f - 1.930f * cosf(t) + 1.290f * cosf(2.0f * t) - 0.388f * cosf(3.0f * t) + 0.028f * cosf(4.0f * t);
+    case 7: {
+        size_t n = (size_t)arg;
+        if ((n != wlen - 1 && n != wlen && n != wlen + 1) || n == 0) return NAN;
+        float v0 = (float)i - (float)(wlen - 1) / 2.0f, v1 = (float)n / 2.0f;
+        return 1.0f - fabsf(v0 / v1);
+    }
+    case 8: {
+        size_t tp = (size_t)arg;
+        if (tp > wlen / 2) return NAN;
+        if (i > wlen - tp - 1) i = wlen - i - 1;
+        return (i < tp) ? 0.5f - 0.5f * cosf(PI_F * ((float)i + 0.5f) / (float)tp) : 1.0f;
+    }
+    case 9: {
+        if (i >= wlen || wlen == 0 || (wlen % 2) != 0) return NAN;
+        size_t m = wlen / 2;
+        if (i >= m) return yo_window_fn(9, wlen - i - 1, wlen, arg);
+        float w0 = 0.0f, w1 = 0.0f;
+        for (size_t j = 0; j <= m; j++) {
+            float w = yo_window_kaiser(j, m + 1, arg);
+            w1 += w;
+            if (j <= i) w0 += w;
+        }
+        return sqrtf(w0 / w1);
+    }
+    default: return NAN;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
  * Synthetic input generator: SplitMix64 used as a COUNTER-based
  * generator (draw u = mix(seed + (u+1)*gamma)), 24-bit uniforms like rand's gen::<f32>(),
  * Box-Muller as src/random/normal.rs:9-22 (real) and :29-44 scaled by 0.70710678 like

@@ -267,3 +267,19 @@ def test_firinterp_generic(oracle, kind):
         oracle.FirInterpolationFilter(kind, 1, h)
     with pytest.raises(ValueError):
         oracle.FirInterpolationFilter(kind, 12, h)
+
+
+# ---- spgram (oracle self-check against the reference's acceptance criterion, small sizes) -------
+@pytest.mark.parametrize("nfft,wtype,wlen,delay", [(64, 5, 32, 16), (100, 1, 100, 25), (96, 9, 48, 24)])
+def test_spgram_oracle_noise_floor(oracle, nfft, wtype, wlen, delay):
+    """spgram.rs:339-367: AWGN at -80 dB -> every PSD bin within +-0.5 dB (here 400*nfft samples, +-1 dB)"""
+    q = oracle.Spgram(nfft, wtype, wlen, delay)
+    n = 400 * nfft
+    x = oracle.gen_complex(77, n) * np.float32(10 ** (-80 / 20))
+    q.write(x)
+    assert q.num_samples == n and q.num_samples_total == n
+    assert q.num_transforms == n // delay
+    psd = q.get_psd()
+    assert np.all(np.abs(psd + 80.0) <= 1.0)
+    q.clear()
+    assert q.num_samples == 0 and q.num_samples_total == n and q.num_transforms == 0

@@ -28,7 +28,7 @@ from ._capi import cf32, lib
 __all__ = [
     "YagiError", "InternalError", "ConfigError", "ValueError_", "RangeError", "ModeError",
     "NoConvergenceError", "DeviceError", "Direction", "dotprod", "FirFilter", "FirDecimationFilter",
-    "FirPfbFilter", "FirInterpolationFilter", "FftFilt", "Fft", "fft_run", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
+    "FirPfbFilter", "FirInterpolationFilter", "FftFilt", "Fft", "fft_run", "Spgram", "WindowType", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
     "fir_design_kaiser", "device_count", "synchronize", "gen_complex_dev", "gen_real_dev",
 ]
 
@@ -589,6 +589,127 @@ def fft_run(input, direction):                               # fft/mod.rs:66-69
     y = np.empty_like(x)
     _check(lib.yagi_hip_fft_run_oneshot(_ptr(x), _ptr(y), x.size, Direction(direction).value))
     return y
+
+
+class WindowType(enum.IntEnum):
+    """math::WindowType (src/math/windows.rs:7-18)"""
+    Unknown = 0
+    Hamming = 1
+    Hann = 2
+    BlackmanHarris = 3
+    BlackmanHarris7 = 4
+    Kaiser = 5
+    FlatTop = 6
+    Triangular = 7
+    RcosTaper = 8
+    Kbd = 9
+
+
+class Spgram(_Handle):
+    """fft::Spgram<T> (src/fft/spgram.rs); T = Complex32 (dtype complex64) or f32 (float32)."""
+
+    def __init__(self, nfft, wtype, window_len, delay, dtype=np.complex64):      # new() :49-125
+        self._set_type(dtype)
+        hd = C.c_void_p()
+        _check(self._fn("create")(nfft, int(wtype), window_len, delay, C.byref(hd)))
+        self._h = hd
+
+    def _set_type(self, dtype):
+        self.T = np.dtype(dtype).type
+        if self.T not in (np.complex64, np.float32):
+            raise ConfigError("Spgram sample type must be complex64 or float32")
+        self._prefix = "yagi_hip_spgramcf_" if self.T is np.complex64 else "yagi_hip_spgramf_"
+        self._Tc = cf32 if self.T is np.complex64 else C.c_float
+
+    @classmethod
+    def default(cls, nfft, dtype=np.complex64):                                  # :128-131
+        self = object.__new__(cls)
+        self._set_type(dtype)
+        hd = C.c_void_p()
+        _check(self._fn("create_default")(nfft, C.byref(hd)))
+        self._h = hd
+        return self
+
+    def clear(self):
+        _check(self._fn("clear")(self._h))
+
+    def set_alpha(self, alpha):
+        _check(self._fn("set_alpha")(self._h, alpha))
+
+    def get_alpha(self):
+        a = C.c_float()
+        _check(self._fn("get_alpha")(self._h, C.byref(a)))
+        return a.value
+
+    def set_freq(self, f):
+        _check(self._fn("set_freq")(self._h, f))
+
+    def set_rate(self, r):
+        _check(self._fn("set_rate")(self._h, r))
+
+    def _params(self):
+        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+        _check(self._fn("get_params")(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, WindowType(d.value)
+
+    def get_nfft(self):
+        return self._params()[0]
+
+    def get_window_len(self):
+        return self._params()[1]
+
+    def get_delay(self):
+        return self._params()[2]
+
+    def get_wtype(self):
+        return self._params()[3]
+
+    def _counters(self):
+        v = [C.c_uint64() for _ in range(4)]
+        _check(self._fn("get_counters")(self._h, *[C.byref(t) for t in v]))
+        return [t.value for t in v]
+
+    def get_num_samples(self):
+        return self._counters()[0]
+
+    def get_num_samples_total(self):
+        return self._counters()[1]
+
+    def get_num_transforms(self):
+        return self._counters()[2]
+
+    def get_num_transforms_total(self):
+        return self._counters()[3]
+
+    def push(self, x):                                                           # :237-251
+        _check(self._fn("push")(self._h, _byval(x, self._Tc)))
+
+    def write(self, x):                                                          # :254-258
+        x = _arr(x, self.T)
+        _check(self._fn("write")(self._h, _ptr(x), x.size))
+
+    def write_dev(self, x_dev, n):
+        _check(self._fn("write_dev")(self._h, _devptr(x_dev), n))
+
+    def get_psd_mag(self):                                                       # :292-304
+        out = np.empty(self.get_nfft(), np.float32)
+        _check(self._fn("get_psd_mag")(self._h, _ptr(out), out.size))
+        return out
+
+    def get_psd(self):                                                           # :308-316
+        out = np.empty(self.get_nfft(), np.float32)
+        with np.errstate(divide="ignore"):
+            _check(self._fn("get_psd")(self._h, _ptr(out), out.size))
+        return out
+
+    @classmethod
+    def estimate_psd(cls, nfft, x, dtype=np.complex64):                          # :319-330
+        T = np.dtype(dtype).type
+        x = _arr(x, T)
+        out = np.empty(nfft, np.float32)
+        fn = lib.yagi_hip_spgramcf_estimate_psd if T is np.complex64 else lib.yagi_hip_spgramf_estimate_psd
+        _check(fn(nfft, _ptr(x), x.size, _ptr(out)))
+        return out
 
 
 # ---- headline stream ----------------------------------------------------------------------------

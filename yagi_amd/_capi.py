@@ -153,6 +153,27 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
 
 _sig("yagi_hip_firfilt_crcf_set_kernel", vp, ci)
 
+for _k, _T in (("cf", cf32), ("f", f32)):
+    p = f"yagi_hip_spgram{_k}_"
+    _sig(p + "create", sz, ci, sz, sz, pvp)
+    _sig(p + "create_default", sz, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "clear", vp)
+    _sig(p + "reset", vp)
+    _sig(p + "set_alpha", vp, f32)
+    _sig(p + "get_alpha", vp, C.POINTER(f32))
+    _sig(p + "set_freq", vp, f32)
+    _sig(p + "set_rate", vp, f32)
+    _sig(p + "get_params", vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(ci))
+    _sig(p + "get_counters", vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64))
+    _sig(p + "push", vp, _T)
+    _sig(p + "write", vp, vp, sz)
+    _sig(p + "write_dev", vp, vp, sz)
+    _sig(p + "get_psd_mag", vp, vp, sz)
+    _sig(p + "get_psd", vp, vp, sz)
+    _sig(p + "estimate_psd", sz, vp, sz, vp)
+
 _sig("yagi_hip_fft_create", sz, ci, pvp)
 _sig("yagi_hip_fft_destroy", vp)
 _sig("yagi_hip_fft_clone", vp, pvp)

@@ -17,6 +17,7 @@
 namespace yagi {
 
 int design_kaiser(size_t n, float fc, float as_, float mu, std::vector<float> &h);   // host.cpp
+int window_value(int type, size_t i, size_t wlen, float arg, float *out);            // host.cpp
 
 static int require_device() {
     static int ok = -1;
@@ -1110,6 +1111,257 @@ struct FirInterp {
 YAGI_FIRINTERP_IMPL(rrrf, RRRF, float, float)
 YAGI_FIRINTERP_IMPL(crcf, CRCF, yagi_cf32, float)
 YAGI_FIRINTERP_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
+
+// ---- Spgram (src/fft/spgram.rs) -----------------------------------------------------------------------
+namespace yagi {
+
+template <class T>
+struct SpgramObj {
+    hipStream_t st = nullptr;
+    int nfft = 0, wtype = 0, wlen = 0, delay = 0;
+    float alpha = 1.0f, gamma = 1.0f;
+    bool accumulate = true;
+    DevWindow<T> buf;
+    DevBuf w, psd, out, tbuf, fbuf;
+    FftPlan plan;
+    Workspace ws;
+    std::vector<T> queue;                // samples push()ed since the last flush
+    size_t sample_timer = 0;
+    uint64_t num_samples = 0, num_samples_total = 0, num_transforms = 0, num_transforms_total = 0;
+    float frequency = 0.0f, sample_rate = -1.0f;
+
+    int init(size_t nfft_, int wtype_, size_t wlen_, size_t delay_) {
+        if (nfft_ < 2) return fail(YAGI_ERR_CONFIG, "fft size must be at least 2");
+        if (wlen_ > nfft_) return fail(YAGI_ERR_CONFIG, "window size cannot exceed fft size");
+        if (wlen_ == 0) return fail(YAGI_ERR_CONFIG, "window size must be greater than zero");
+        if (wtype_ == YAGI_WINDOW_KAISER && wlen_ % 2 != 0)              // spgram.rs:60-62 (sic)
+            return fail(YAGI_ERR_CONFIG, "KBD window length must be even");
+        if (delay_ == 0) return fail(YAGI_ERR_CONFIG, "delay must be greater than 0");
+        if (wtype_ < 1 || wtype_ > 9) return fail(YAGI_ERR_CONFIG, "unknown window type");
+        if (nfft_ > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %zu not supported (max %d)", nfft_, kFftMaxLds);
+        YG_TRY(require_device());
+        nfft = (int)nfft_; wtype = wtype_; wlen = (int)wlen_; delay = (int)delay_;
+        // taper (spgram.rs:93-119): window, then normalise to unit energy
+        std::vector<float> wv(wlen_);
+        float g = 0.0f;
+        for (size_t i = 0; i < wlen_; ++i) {
+            float arg = 0.0f;
+            switch (wtype) {
+                case YAGI_WINDOW_KAISER: arg = 10.0f; break;
+                case YAGI_WINDOW_KBD: arg = 3.0f; break;
+                case YAGI_WINDOW_TRIANGULAR: arg = (float)wlen_; break;
+                case YAGI_WINDOW_RCOSTAPER: arg = (float)(wlen_ / 3); break;
+                default: break;
+            }
+            YG_TRY(window_value(wtype, i, wlen_, arg, &wv[i]));
+            g += wv[i] * wv[i];
+        }
+        g = 1.0f / std::sqrt(g);
+        for (auto &v : wv) v = g * v;
+        YG_TRY(w.alloc(wlen_ * sizeof(float)));
+        YG_TRY(upload(w.p, wv.data(), wlen_ * sizeof(float), st));
+        YG_TRY(psd.alloc(nfft_ * sizeof(float)));
+        YG_TRY(out.alloc(nfft_ * sizeof(float)));
+        YG_TRY(fft_plan_init(plan, nfft_, YAGI_FFT_FORWARD));
+        YG_TRY(buf.init(wlen, st));
+        set_alpha_unchecked(-1.0f);
+        return reset();
+    }
+    void set_alpha_unchecked(float a) {
+        accumulate = (a == -1.0f);
+        if (accumulate) { alpha = 1.0f; gamma = 1.0f; } else { alpha = a; gamma = 1.0f - a; }
+    }
+    int clear() {                                                    // :135-147
+        queue.clear();
+        sample_timer = (size_t)delay;
+        num_transforms = 0;
+        num_samples = 0;
+        YG_HIP(hipMemsetAsync(psd.p, 0, (size_t)nfft * sizeof(float), st));
+        return YAGI_OK;
+    }
+    int reset() {                                                    // :150-155
+        YG_TRY(clear());
+        YG_TRY(buf.reset(st));
+        num_samples_total = 0;
+        num_transforms_total = 0;
+        return YAGI_OK;
+    }
+    // transforms whose newest sample is X[first + f*delay], f < nframes (X = window ++ x)
+    int run_frames(const T *x, long long first, size_t nframes) {
+        const size_t chunk = 8192;
+        for (size_t f0 = 0; f0 < nframes; f0 += chunk) {
+            const size_t nf = (nframes - f0) < chunk ? (nframes - f0) : chunk;
+            YG_TRY(tbuf.ensure(nf * (size_t)nfft * sizeof(cf32)));
+            YG_TRY(fbuf.ensure(nf * (size_t)nfft * sizeof(cf32)));
+            YG_TRY(launch_spgram_frames<T>(buf.dev(), x, w.as<float>(), wlen, nfft, first + (long long)f0 * delay, delay,
+                                           nf, tbuf.as<cf32>(), st));
+            YG_TRY(launch_fft_batch(plan.d, tbuf.as<cf32>(), fbuf.as<cf32>(), nf, st));
+            YG_TRY(launch_spgram_accum(fbuf.as<cf32>(), nfft, nf, alpha, gamma, num_transforms == 0, psd.as<float>(), st));
+            num_transforms += nf;
+            num_transforms_total += nf;
+        }
+        return YAGI_OK;
+    }
+    int write_dev(const T *x, size_t n) {                            // push() x n, :237-259
+        if (n == 0) return YAGI_OK;
+        const size_t t = sample_timer;                               // 1..delay pushes until the next transform
+        size_t nframes = 0;
+        if (n >= t) nframes = (n - t) / (size_t)delay + 1;
+        if (nframes) YG_TRY(run_frames(x, (long long)t - 1, nframes));
+        sample_timer = (n < t) ? t - n : (size_t)delay - (n - t) % (size_t)delay;
+        num_samples += n;
+        num_samples_total += n;
+        return buf.advance(x, n, st);
+    }
+    int write_host(const T *x, size_t n) {
+        if (n == 0) return YAGI_OK;
+        YG_TRY(ws.x.ensure(n * sizeof(T)));
+        YG_TRY(upload(ws.x.p, x, n * sizeof(T), st));
+        return write_dev(ws.x.as<T>(), n);
+    }
+    int flush() {
+        if (queue.empty()) return YAGI_OK;
+        std::vector<T> q2;
+        q2.swap(queue);
+        return write_host(q2.data(), q2.size());
+    }
+    int get(float *o, size_t n, bool db) {                           // :292-316
+        if (n < (size_t)nfft) return fail(YAGI_ERR_CONFIG, "psd buffer must hold nfft values");
+        YG_TRY(flush());
+        const uint64_t nt = num_transforms ? num_transforms : 1;
+        const float scale = accumulate ? 1.0f / (float)nt : 0.0f;    // the reference's 0.0 when not accumulating
+        YG_TRY(launch_spgram_psd(psd.as<float>(), nfft, scale, db, out.as<float>(), st));
+        return download(o, out.p, (size_t)nfft * sizeof(float), st);
+    }
+};
+
+}  // namespace yagi
+
+#define YAGI_SPGRAM_IMPL(K, T)                                                                      \
+    struct yagi_hip_spgram##K##_s : SpgramObj<T> {};                                                \
+    extern "C" {                                                                                    \
+    int yagi_hip_spgram##K##_create(size_t nfft, int wtype, size_t window_len, size_t delay,        \
+                                    yagi_hip_spgram##K *q) {                                        \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        auto o = std::make_unique<yagi_hip_spgram##K##_s>();                                        \
+        YG_TRY(o->init(nfft, wtype, window_len, delay));                                            \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_create_default(size_t nfft, yagi_hip_spgram##K *q) {                   \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (nfft < 2) return fail(YAGI_ERR_CONFIG, "fft size must be at least 2");                  \
+        return yagi_hip_spgram##K##_create(nfft, YAGI_WINDOW_KAISER, nfft / 2, nfft / 4, q);        \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_destroy(yagi_hip_spgram##K q) {                                        \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_set_stream(yagi_hip_spgram##K q, yagi_stream_t s) {                    \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_clear(yagi_hip_spgram##K q) {                                          \
+        CHECK_Q(q);                                                                                 \
+        YG_TRY(q->flush());                                                                         \
+        return q->clear();                                                                          \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_reset(yagi_hip_spgram##K q) {                                          \
+        CHECK_Q(q);                                                                                 \
+        return q->reset();                                                                          \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_set_alpha(yagi_hip_spgram##K q, float alpha) {                         \
+        CHECK_Q(q);                                                                                 \
+        if (alpha != -1.0f && (alpha < 0.0f || alpha > 1.0f))                                       \
+            return fail(YAGI_ERR_CONFIG, "alpha must be in {-1,[0,1]}");                            \
+        YG_TRY(q->flush());                                                                         \
+        q->set_alpha_unchecked(alpha);                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_get_alpha(yagi_hip_spgram##K q, float *alpha) {                        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(alpha);                                                                           \
+        *alpha = q->alpha;                                                                          \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_set_freq(yagi_hip_spgram##K q, float freq) {                           \
+        CHECK_Q(q);                                                                                 \
+        q->frequency = freq;                                                                        \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_set_rate(yagi_hip_spgram##K q, float rate) {                           \
+        CHECK_Q(q);                                                                                 \
+        if (rate <= 0.0f) return fail(YAGI_ERR_CONFIG, "sample rate must be greater than zero");    \
+        q->sample_rate = rate;                                                                      \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_get_params(yagi_hip_spgram##K q, size_t *nfft, size_t *window_len,     \
+                                        size_t *delay, int *wtype) {                                \
+        CHECK_Q(q);                                                                                 \
+        if (nfft) *nfft = (size_t)q->nfft;                                                          \
+        if (window_len) *window_len = (size_t)q->wlen;                                              \
+        if (delay) *delay = (size_t)q->delay;                                                       \
+        if (wtype) *wtype = q->wtype;                                                               \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_get_counters(yagi_hip_spgram##K q, uint64_t *ns, uint64_t *nst,        \
+                                          uint64_t *nt, uint64_t *ntt) {                            \
+        CHECK_Q(q);                                                                                 \
+        YG_TRY(q->flush());                                                                         \
+        if (ns) *ns = q->num_samples;                                                               \
+        if (nst) *nst = q->num_samples_total;                                                       \
+        if (nt) *nt = q->num_transforms;                                                            \
+        if (ntt) *ntt = q->num_transforms_total;                                                    \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_push(yagi_hip_spgram##K q, T x) {                                      \
+        CHECK_Q(q);                                                                                 \
+        q->queue.push_back(x);                                                                      \
+        if (q->queue.size() >= (size_t)1 << 20) return q->flush();                                  \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_write(yagi_hip_spgram##K q, const T *x, size_t n) {                    \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        YG_TRY(q->flush());                                                                         \
+        return q->write_host(x, n);                                                                 \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_write_dev(yagi_hip_spgram##K q, const T *x, size_t n) {                \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        YG_TRY(q->flush());                                                                         \
+        return q->write_dev(x, n);                                                                  \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_get_psd_mag(yagi_hip_spgram##K q, float *psd, size_t n) {              \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(psd);                                                                             \
+        return q->get(psd, n, false);                                                               \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_get_psd(yagi_hip_spgram##K q, float *psd, size_t n) {                  \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(psd);                                                                             \
+        return q->get(psd, n, true);                                                                \
+    }                                                                                               \
+    int yagi_hip_spgram##K##_estimate_psd(size_t nfft, const T *x, size_t n, float *psd) {          \
+        CHECK_PTR(psd);                                                                             \
+        if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        yagi_hip_spgram##K q = nullptr;                                                             \
+        YG_TRY(yagi_hip_spgram##K##_create_default(nfft, &q));                                      \
+        std::unique_ptr<yagi_hip_spgram##K##_s> guard(q);                                           \
+        YG_TRY(q->write_host(x, n));                                                                \
+        if (q->num_transforms == 0) YG_TRY(q->run_frames(nullptr, -1, 1));   /* q.step() :325-327 */ \
+        return q->get(psd, nfft, true);                                                             \
+    }                                                                                               \
+    }
+
+YAGI_SPGRAM_IMPL(cf, yagi_cf32)
+YAGI_SPGRAM_IMPL(f, float)
 
 // ---- FftFilt ---------------------------------------------------------------------------------------
 namespace yagi {

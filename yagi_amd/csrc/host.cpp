@@ -96,6 +96,65 @@ int design_kaiser(size_t n, float fc, float as_, float mu, std::vector<float> &h
     return YAGI_OK;
 }
 
+// ---- taper windows for Spgram (math/windows.rs:76-205), single precision like the reference -------
+// type: 1 Hamming, 2 Hann, 3 BlackmanHarris, 4 BlackmanHarris7, 5 Kaiser, 6 FlatTop, 7 Triangular,
+//       8 RcosTaper, 9 Kbd (the reference's WindowType discriminants)
+static float kaiser_window(size_t i, size_t wlen, float beta) {
+    const float t = static_cast<float>(i) - static_cast<float>(wlen - 1) / 2.0f;
+    const float r = 2.0f * t / static_cast<float>(wlen - 1);
+    return bessel_i0(beta * std::sqrt(1.0f - r * r)) / bessel_i0(beta);
+}
+
+int window_value(int type, size_t i, size_t wlen, float arg, float *out) {
+    const float pi = 3.14159265358979323846f;
+    const float t = 2.0f * pi * static_cast<float>(i) / static_cast<float>(wlen - 1);
+    switch (type) {
+        case 1: *out = 0.53836f - 0.46164f * std::cos((2.0f * pi * static_cast<float>(i)) / static_cast<float>(wlen - 1)); return YAGI_OK;
+        case 2: *out = 0.5f - 0.5f * std::cos((2.0f * pi * static_cast<float>(i)) / static_cast<float>(wlen - 1)); return YAGI_OK;
+        case 3: *out = 0.35875f - 0.48829f * std::cos(t) + 0.14128f * std::cos(2.0f * t) - 0.01168f * std::cos(3.0f * t); return YAGI_OK;
+        case 4:
+            *out = 0.27105f - 0.43329f * std::cos(t) + 0.21812f * std::cos(2.0f * t) - 0.06592f * std::cos(3.0f * t) +
+                   0.01081f * std::cos(4.0f * t) - 0.00077f * std::cos(5.0f * t) + 0.00001f * std::cos(6.0f * t);
+            return YAGI_OK;
+        case 5:
+            if (arg < 0.0f) return fail(YAGI_ERR_VALUE, "Kaiser window: beta must be greater than or equal to zero");
+            *out = kaiser_window(i, wlen, arg);
+            return YAGI_OK;
+        case 6: *out = 1.000f - 1.930f * std::cos(t) + 1.290f * std::cos(2.0f * t) - 0.388f * std::cos(3.0f * t) + 0.028f * std::cos(4.0f * t); return YAGI_OK;
+        case 7: {
+            const size_t n = static_cast<size_t>(arg);
+            if (n + 1 != wlen && n != wlen && n != wlen + 1)
+                return fail(YAGI_ERR_VALUE, "Triangular window: sub-length must be in wlen+{-1,0,1}");
+            if (n == 0) return fail(YAGI_ERR_VALUE, "Triangular window: sub-length must be greater than zero");
+            const float v0 = static_cast<float>(i) - static_cast<float>(wlen - 1) / 2.0f;
+            *out = 1.0f - std::fabs(v0 / (static_cast<float>(n) / 2.0f));
+            return YAGI_OK;
+        }
+        case 8: {
+            const size_t tp = static_cast<size_t>(arg);
+            if (tp > wlen / 2) return fail(YAGI_ERR_VALUE, "Raised-cosine taper window: taper length cannot exceed half window length");
+            size_t ii = i;
+            if (ii > wlen - tp - 1) ii = wlen - ii - 1;
+            *out = (ii < tp) ? 0.5f - 0.5f * std::cos(pi * (static_cast<float>(ii) + 0.5f) / static_cast<float>(tp)) : 1.0f;
+            return YAGI_OK;
+        }
+        case 9: {
+            if (wlen % 2 != 0) return fail(YAGI_ERR_VALUE, "KBD window: window length must be even");
+            const size_t m = wlen / 2;
+            const size_t ii = (i >= m) ? wlen - i - 1 : i;
+            float w0 = 0.0f, w1 = 0.0f;
+            for (size_t j = 0; j <= m; ++j) {
+                const float wv = kaiser_window(j, m + 1, arg);
+                w1 += wv;
+                if (j <= ii) w0 += wv;
+            }
+            *out = std::sqrt(w0 / w1);
+            return YAGI_OK;
+        }
+        default: return fail(YAGI_ERR_CONFIG, "unknown window type");
+    }
+}
+
 }  // namespace yagi
 
 extern "C" {

@@ -87,6 +87,14 @@ template <class T, class C>
 int launch_fftfilt_ola(const cf32 *t, const cf32 *w, int n, size_t nblocks, C scale, T *y, cf32 *w_next,
                        hipStream_t st);
 
+// ---- spgram_kernels.hip (fft::Spgram, src/fft/spgram.rs:237-316) ---------------------------------------
+template <class T>
+int launch_spgram_frames(const T *win, const T *x, const float *w, int wlen, int nfft, long long first,
+                         int delay, size_t nframes, cf32 *time, hipStream_t st);
+int launch_spgram_accum(const cf32 *freq, int nfft, size_t nframes, float alpha, float gamma, bool first_ever,
+                        float *psd, hipStream_t st);
+int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float *out, hipStream_t st);
+
 // ---- chan_kernels.hip ----------------------------------------------------------------------
 // firpfbch analyzer: hist = the (p-1)*M samples preceding x[0] (oldest first).
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
