@@ -70,9 +70,12 @@ def main():
                          "(a cold MI355X runs the first ~50 launches up to 25 %% slower); 0 disables")
     ap.add_argument("--frames", type=int, default=BLOCK_FRAMES, help="frames of 4096 samples per step")
     ap.add_argument("--variant", type=int, default=0,
-                    help="0/1 fused direct-form (sliding VALU FIR, default), 2 fused MFMA Toeplitz FIR, "
-                         "3 fast convolution (overlap-save kernel + batched FFT, two launches)")
+                    help="0 auto (= 3 at 256 taps), 1 fused direct-form (sliding VALU FIR), 2 fused MFMA Toeplitz "
+                         "FIR, 3 fast convolution (overlap-save kernel + batched FFT, two launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend for the barrier / max-over-ranks reduction (nccl = RCCL; "
+                         "gloo lets several ranks share one GPU when rehearsing the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,16 +93,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.dist_backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    eff_variant = 3 if args.variant == 0 else args.variant       # library's auto choice at 256 taps
     nframes = args.frames
     n = nframes * NFFT
     h = ya.fir_design_kaiser(TAPS, 0.2, 60.0)        # FirFilter::new_kaiser(256, 0.2, 60, 0)
@@ -142,9 +151,34 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)                   # HIP events on the launch stream
 
     if world > 1:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
+                         device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
+
+    # the same workload through the fused direct-form kernel (dotprod-style FIR), K steps, reported beside
+    # the headline so both algorithms are on record (untimed w.r.t. `value`)
+    direct = None
+    if eff_variant != 1:
+        qd = ya.FirFftStream(h, NFFT)
+        qd.set_scale(scale)
+        qd.set_variant(1)
+        qd.set_stream(stream.cuda_stream)
+        yd = torch.empty(n, dtype=torch.complex64, device=dev)
+        for _ in range(max(args.warmup, 5)):
+            qd.execute_dev(x, nframes, yd)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            qd.execute_dev(x, nframes, yd)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        d_ms = e0.elapsed_time(e1) / args.steps
+        direct = {"value": round(n / d_ms / 1e3, 3), "unit": "Msamples/s per GPU", "ms_per_step": round(d_ms, 4),
+                  "kernel": "firfft_crcf_4096_slide_kernel (fused direct-form FIR + FFT, 16 B/sample)",
+                  "fp32_tflops": round(FLOP_PER_SAMPLE * n / (d_ms / 1e3) / 1e12, 2)}
+        del yd
 
     # in-run parity spot check (rank 0): last frame of the last step vs the oracle (f64 FIR + f64 FFT)
     # on the same input; its 255-sample halo is the preceding samples of the stream
@@ -162,17 +196,18 @@ def main():
         except Exception as e:            # the checker must never hide a bench result
             parity = f"unavailable: {e}"
 
-    kernel_name = {2: "fir_crcf_mfma_kernel<68, true>",
-                   3: "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (two launches per step)"}.get(
-        args.variant, "firfft_crcf_4096_slide_kernel")
+    kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",
+                   3: "firfilt_crcf_fftconv_kernel<true> + fft4096_kernel<-1> (two launches per step)"}[eff_variant]
     # algorithmic bytes per input sample: fused = 8 in + 8 out; the two-kernel fast-convolution form also
     # writes and re-reads the FIR output stream ("32 if run as two kernels -- state which")
-    bytes_per_sample = 32 if args.variant == 3 else BYTES_PER_SAMPLE
+    bytes_per_sample = 32 if eff_variant == 3 else BYTES_PER_SAMPLE
+    # executed flops per input sample: direct 4*L + FFT 60; fast convolution 2 FFTs per 3841 outputs + product + FFT
+    flop_per_sample = round(2 * 60 * 4096 / 3841 + 6 + 60) if eff_variant == 3 else FLOP_PER_SAMPLE
     traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/traffic.json)
     try:
         tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
         if tj.get("samples_per_launch") == n:
-            traffic = tj["kernels"][kernel_name]["hbm_bytes"]
+            traffic = tj["variants"][str(eff_variant)]["hbm_bytes"]
     except Exception:
         traffic = None
 
@@ -195,7 +230,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "firfilt_crcf 256-tap (kaiser 0.2/60dB, scale 0.4) -> 4096-pt forward FFT, "
-                                   "fused, streaming complex f32 (BASELINE configs[1] feeding configs[2])",
+                                   "streaming complex f32 (BASELINE configs[1] feeding configs[2])",
+                       "algorithm": ("fast convolution (overlap-save, 4096-pt blocks) + batched FFT" if eff_variant == 3
+                                     else "fused direct-form FIR + FFT"),
                        "samples_per_step_per_gpu": n, "frames_per_step": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
                        "kernel": kernel_name, "variant": args.variant, "prewarm_ms": args.prewarm_ms},
@@ -205,11 +242,14 @@ def main():
                                            "profiles/traffic.json" if traffic else None,
                          "kernel_ms": round(kern_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": bytes_per_sample * n,
-                         "note": "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32",
-                         "fp32": {"achieved_tflops": round(FLOP_PER_SAMPLE * n / kern_s / 1e12, 2),
-                                  "peak_tflops": FP32_PEAK_TFLOPS,
-                                  "frac": round(FLOP_PER_SAMPLE * n / kern_s / 1e12 / FP32_PEAK_TFLOPS, 4)}},
+                         "note": ("fast convolution: overlap-save FIR kernel + batched FFT, FIR output stream crosses HBM once"
+                                  if eff_variant == 3 else
+                                  "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32"),
+                         "fp32": {"achieved_tflops": round(flop_per_sample * n / kern_s / 1e12, 2),
+                                  "peak_tflops": FP32_PEAK_TFLOPS, "flop_per_sample": flop_per_sample,
+                                  "frac": round(flop_per_sample * n / kern_s / 1e12 / FP32_PEAK_TFLOPS, 4)}},
             "parity_rel_l2_vs_f64": parity,
+            "direct_form": direct,
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle

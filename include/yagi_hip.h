@@ -353,7 +353,7 @@ int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q);
 int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s);
 int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale);
 int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q);
-/* variant: 0 = auto (= 1), 1 = fused, register-sliding VALU FIR, 2 = fused, MFMA Toeplitz FIR (<= 256 taps),
+/* variant: 0 = auto (3 for 96..2049 taps, else 1), 1 = fused, register-sliding VALU FIR, 2 = fused, MFMA Toeplitz FIR (<= 256 taps),
  * 3 = fast convolution (overlap-save kernel, then batched FFT; <= 2049 taps).  Variant 3 agrees with 1/2 to
  * f32 rounding but is not exact for integer inputs. */
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant);

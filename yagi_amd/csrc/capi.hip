@@ -1570,7 +1570,10 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_PTR(spectra);
     auto &f = q->fir;
     YG_TRY(f.w.flush(f.st));
-    if (q->variant == 3) {
+    // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
+    // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
+    const bool use_conv = q->variant == 3 || (q->variant == 0 && f.L >= 96 && f.L <= 2049);
+    if (use_conv) {
         // fast-convolution form (two kernels): overlap-save FIR into a scratch stream, then the batched
         // 4096-point FFT over its frames.  32 B/sample of HBM traffic instead of 16.  (Running the two
         // kernels as a chunked two-stream pipeline was measured slower: profiles/r01_notes.md.)

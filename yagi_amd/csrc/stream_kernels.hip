@@ -369,17 +369,22 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
 // ---------------------------------------------------------------------------------------------
 // x[-pre .. x_avail) is readable (pre = samples of the same stream stored in front of x[0], used when a
 // long block is processed in chunks); older samples come from `win` (the L-sample filter window).
+// INTERIOR = every block of the launch lies inside x (no window, no end-of-stream checks): the common
+// case gets a branch-free instance that needs no AGPR spill space (256 VGPRs -> 2 waves/SIMD instead of
+// 1: 0.129 -> 0.088 ms); the few boundary blocks go to the general instance in their own small launches.
+// (One launch with LDS-staged boundary blocks measured slower: 0.094 ms, profiles/r01_notes.md.)
+template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
 firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x, long long pre,
                             long long x_avail, const float2 *__restrict__ hs, float sc, int L, int V,
                             const float2 *__restrict__ twf, const float2 *__restrict__ twb,
-                            float2 *__restrict__ y, size_t ny) {
+                            float2 *__restrict__ y, size_t ny, size_t b_first, size_t b_count) {
     __shared__ float2 lds[kFft4096LdsFloat2];
-    const size_t nblk = (ny + V - 1) / V;
-    for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    for (size_t bi = blockIdx.x; bi < b_count; bi += gridDim.x) {
+        const size_t b = b_first + bi;
         const long long base = (long long)b * V - (L - 1);
         float2 v[16];
-        if (base >= -pre && base + 4096 <= x_avail) {
+        if (INTERIOR) {
             const float2 *src = x + base;
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = src[256 * a + threadIdx.x];
@@ -406,7 +411,8 @@ firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__rest
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
             const int n = (int)threadIdx.x + 256 * d - (L - 1);
-            if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
+            if (INTERIOR) { if (n >= 0) y[o0 + n] = v[d]; }
+            else if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
         }
     }
 }
@@ -418,13 +424,32 @@ int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x
     if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
     const int V = 4096 - (L - 1);
     const size_t nblk = (ny + V - 1) / V;
-    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
-    firfilt_crcf_fftconv_kernel<<<grid, 256, 0, st>>>(
-        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), (long long)pre,
-        (long long)x_avail, reinterpret_cast<const float2 *>(hs), scale / 4096.0f, L, V,
-        reinterpret_cast<const float2 *>(twf), reinterpret_cast<const float2 *>(twb),
-        reinterpret_cast<float2 *>(y), ny);
-    YG_LAUNCH_CHECK();
+    // interior blocks: base >= -pre, base + 4096 <= x_avail, and the whole valid part lies inside y
+    size_t b_lo = 0;
+    while (b_lo < nblk && (long long)b_lo * V - (L - 1) < -(long long)pre) ++b_lo;
+    size_t b_hi = nblk;
+    while (b_hi > b_lo && ((b_hi - 1) * (size_t)V + 4096 - (size_t)(L - 1) > x_avail || b_hi * (size_t)V > ny)) --b_hi;
+    const float2 *fw = reinterpret_cast<const float2 *>(win), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *fh = reinterpret_cast<const float2 *>(hs), *f1 = reinterpret_cast<const float2 *>(twf);
+    const float2 *f2 = reinterpret_cast<const float2 *>(twb);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    const float sc = scale / 4096.0f;
+    auto grid_of = [](size_t n) { return (unsigned)(n < 65536 ? n : 65536); };
+    if (b_lo > 0) {
+        firfilt_crcf_fftconv_kernel<false><<<grid_of(b_lo), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc, L, V,
+                                                                         f1, f2, fy, ny, 0, b_lo);
+        YG_LAUNCH_CHECK();
+    }
+    if (b_hi > b_lo) {
+        firfilt_crcf_fftconv_kernel<true><<<grid_of(b_hi - b_lo), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc,
+                                                                                 L, V, f1, f2, fy, ny, b_lo, b_hi - b_lo);
+        YG_LAUNCH_CHECK();
+    }
+    if (nblk > b_hi) {
+        firfilt_crcf_fftconv_kernel<false><<<grid_of(nblk - b_hi), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc,
+                                                                                  L, V, f1, f2, fy, ny, b_hi, nblk - b_hi);
+        YG_LAUNCH_CHECK();
+    }
     return YAGI_OK;
 }
 
