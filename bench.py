@@ -159,10 +159,10 @@ def main():
     # the same workload through the fused direct-form kernel (dotprod-style FIR), K steps, reported beside
     # the headline so both algorithms are on record (untimed w.r.t. `value`)
     direct = None
-    if eff_variant != 1:
+    if eff_variant == 3:
         qd = ya.FirFftStream(h, NFFT)
         qd.set_scale(scale)
-        qd.set_variant(1)
+        qd.set_variant(2)                 # fused MFMA Toeplitz FIR + FFT: the faster of the two direct forms
         qd.set_stream(stream.cuda_stream)
         yd = torch.empty(n, dtype=torch.complex64, device=dev)
         for _ in range(max(args.warmup, 5)):
@@ -176,7 +176,7 @@ def main():
         torch.cuda.synchronize()
         d_ms = e0.elapsed_time(e1) / args.steps
         direct = {"value": round(n / d_ms / 1e3, 3), "unit": "Msamples/s per GPU", "ms_per_step": round(d_ms, 4),
-                  "kernel": "firfft_crcf_4096_slide_kernel (fused direct-form FIR + FFT, 16 B/sample)",
+                  "kernel": "fir_crcf_mfma_kernel<68, true> (fused direct-form MFMA Toeplitz FIR + FFT, 16 B/sample)",
                   "fp32_tflops": round(FLOP_PER_SAMPLE * n / (d_ms / 1e3) / 1e12, 2)}
         del yd
 

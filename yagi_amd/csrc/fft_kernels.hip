@@ -19,7 +19,9 @@ __global__ void __launch_bounds__(256)
 fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                const float2 *__restrict__ tw, size_t batch) {
     __shared__ float2 lds[kFft4096LdsFloat2];
-    for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
+    {
+        const size_t b = blockIdx.x;          // one transform per workgroup (grid = batch), no grid-stride loop
+        (void)batch;
         const float2 *src = in + b * 4096;
         float2 v[16];
 #pragma unroll
@@ -106,7 +108,8 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
     float2 *fout = reinterpret_cast<float2 *>(out);
     const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
     if (p.n == 4096) {
-        const unsigned grid = (unsigned)(batch < 65536 ? batch : 65536);
+        if (batch > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+        const unsigned grid = (unsigned)batch;
         if (p.dir == YAGI_FFT_FORWARD)
             fft4096_kernel<-1><<<grid, 256, 0, st>>>(fin, fout, tw, batch);
         else

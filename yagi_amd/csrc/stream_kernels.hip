@@ -116,7 +116,10 @@ firfilt_crcf_slide_kernel(const float2 *__restrict__ win, const float2 *__restri
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
     float2 *ys = xs;                         // 4096 outputs, padded rows: reuses the span image once the FIR loop is done
-    for (size_t tile = blockIdx.x; tile * kTile < ny; tile += gridDim.x) {
+    // one tile per workgroup, no grid-stride loop (a loop makes the FFT twiddle / table loads loop-invariant
+    // and LICM keeps them live across the FIR phase: +100 VGPRs in the fused kernels)
+    {
+        const size_t tile = blockIdx.x;
         const size_t o0 = tile * kTile;
         const long long base = (long long)o0 - (Lp - 1);
         stage_span(xs, win, x, base, kTile + Lp, L, (long long)ny);
@@ -147,7 +150,8 @@ firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__re
     float2 *xs = reinterpret_cast<float2 *>(smem);
     float2 *fl = xs;                         // FIR-output image, then the FFT exchanges: reuses the span image
     const long long x_len = (long long)nframes * kTile;
-    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+    {
+        const size_t f = blockIdx.x;        // one frame per workgroup, no grid-stride loop (see above)
         const long long base = (long long)f * kTile - (Lp - 1);
         stage_span(xs, win, x, base, kTile + Lp, L, x_len);
         __syncthreads();
@@ -264,7 +268,9 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
     // FUSED: n_units = frames (tile == frame); else n_units = output samples
     const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
     const long long x_len = FUSED ? (long long)n_units * kTile : (long long)n_units;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    {
+        const size_t tile = blockIdx.x;     // one tile per workgroup, no grid-stride loop
+        (void)ntiles;
         const size_t o0 = tile * kTile;
 #ifndef YG_ABL_NOSTAGE
         stage_span(xs, win, x, (long long)o0 - (Lp - 1), kTile + Lp, L, x_len);
@@ -326,7 +332,8 @@ static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW>), raised));
     const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)(ntiles < 65536 ? ntiles : 65536);
+    if (ntiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const unsigned grid = (unsigned)ntiles;
     fir_crcf_mfma_kernel<NS, FUSED, NW><<<grid, 64 * NW, slide_lds_bytes(Lp), st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, Lp, scale,
         reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units);
@@ -373,21 +380,28 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
 // case gets a branch-free instance that needs no AGPR spill space (256 VGPRs -> 2 waves/SIMD instead of
 // 1: 0.129 -> 0.088 ms); the few boundary blocks go to the general instance in their own small launches.
 // (One launch with LDS-staged boundary blocks measured slower: 0.094 ms, profiles/r01_notes.md.)
+#ifndef YG_CONV_WAVES
+#define YG_CONV_WAVES 2
+#endif
 template <bool INTERIOR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, INTERIOR ? YG_CONV_WAVES : 1)
 firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x, long long pre,
                             long long x_avail, const float2 *__restrict__ hs, float sc, int L, int V,
                             const float2 *__restrict__ twf, const float2 *__restrict__ twb,
                             float2 *__restrict__ y, size_t ny, size_t b_first, size_t b_count) {
     __shared__ float2 lds[kFft4096LdsFloat2];
-    for (size_t bi = blockIdx.x; bi < b_count; bi += gridDim.x) {
-        const size_t b = b_first + bi;
+    // exactly one block per workgroup and NO grid-stride loop: inside a loop the twiddle and FFT{h} loads
+    // are loop-invariant, LICM hoists all 48 of them to the prologue and they stay live (or spilled) across
+    // both transforms
+    {
+        const size_t b = b_first + blockIdx.x;
+        (void)b_count;
         const long long base = (long long)b * V - (L - 1);
         float2 v[16];
         if (INTERIOR) {
-            const float2 *src = x + base;
+            const float2 *src = x + base;            // block-uniform base (SGPRs) + 32-bit lane offset
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = src[256 * a + threadIdx.x];
+            for (unsigned a = 0; a < 16; ++a) v[a] = src[256u * a + threadIdx.x];
         } else {
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -400,19 +414,31 @@ firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__rest
         }
         // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
         fft4096_passes_to_regs<-1>(v, lds, twf);
+#ifdef YG_CONV_FENCE
+        __builtin_amdgcn_sched_barrier(0);      // keep the 16 hs loads below the forward transform
+#endif
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const float2 p = cmul(v[d], hs[threadIdx.x + 256 * d]);
+        for (unsigned d = 0; d < 16; ++d) {
+            const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
             v[d] = make_float2(p.x * sc, p.y * sc);
         }
         fft4096_passes_to_regs<+1>(v, lds, twb);
         // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
         const size_t o0 = b * (size_t)V;
+        if (INTERIOR) {
+            // yb[n] with n = t + 256 d >= L-1: block-uniform base, 32-bit lane offsets
+            float2 *yb = y + o0 - (size_t)(L - 1);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const int n = (int)threadIdx.x + 256 * d - (L - 1);
-            if (INTERIOR) { if (n >= 0) y[o0 + n] = v[d]; }
-            else if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
+            for (unsigned d = 0; d < 16; ++d) {
+                const unsigned n = threadIdx.x + 256u * d;
+                if (n >= (unsigned)(L - 1)) yb[n] = v[d];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const int n = (int)threadIdx.x + 256 * d - (L - 1);
+                if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
+            }
         }
     }
 }
@@ -434,7 +460,8 @@ int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x
     const float2 *f2 = reinterpret_cast<const float2 *>(twb);
     float2 *fy = reinterpret_cast<float2 *>(y);
     const float sc = scale / 4096.0f;
-    auto grid_of = [](size_t n) { return (unsigned)(n < 65536 ? n : 65536); };
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    auto grid_of = [](size_t n) { return (unsigned)n; };
     if (b_lo > 0) {
         firfilt_crcf_fftconv_kernel<false><<<grid_of(b_lo), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc, L, V,
                                                                          f1, f2, fy, ny, 0, b_lo);
@@ -461,7 +488,8 @@ int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad,
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(firfilt_crcf_slide_kernel), raised));
     size_t tiles = (ny + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)(tiles < 65536 ? tiles : 65536);
+    if (tiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const unsigned grid = (unsigned)tiles;
     firfilt_crcf_slide_kernel<<<grid, 256, slide_lds_bytes(Lp), st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), taps_pad, L, Lp,
         scale, reinterpret_cast<float2 *>(y), ny);
@@ -480,7 +508,8 @@ int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pa
     }
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(firfft_crcf_4096_slide_kernel), raised));
-    const unsigned grid = (unsigned)(nframes < 65536 ? nframes : 65536);
+    if (nframes > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const unsigned grid = (unsigned)nframes;
     firfft_crcf_4096_slide_kernel<<<grid, 256, slide_lds_bytes(Lp), st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), taps_pad, L, Lp,
         scale, reinterpret_cast<const float2 *>(tw4096), reinterpret_cast<float2 *>(spectra), nframes);
