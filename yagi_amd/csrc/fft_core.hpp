@@ -83,9 +83,8 @@ __device__ __forceinline__ void twiddle_powers(float2 (&w)[16], const float2 *__
 // v[a] = x[256a + b].  `lds` is a kFft4096LdsFloat2 float2 buffer nobody else touches; `tw` is
 // the W_4096^m table (sign already per direction).  Output goes to out[k], k in [0,4096).
 // Contains 4 __syncthreads(); all 256 lanes must call it.
-// TWP = twiddles by powers (4 exact loads + products) -- right for the HBM-bound kernels; the fused
-// direct-form kernels are FP32-issue bound instead and keep the 15 table gathers per pass (TWP = false),
-// which cost no VALU work.
+// TWP = twiddles by powers (4 exact loads + products); TWP = false keeps the 15 table gathers per pass
+// (an ablation knob: the gathers were faster only while the fused kernels sat at 2 waves/SIMD).
 template <int SIGN, bool GUARD = false, bool TWP = true>
 __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restrict__ lds,
                                                const float2 *__restrict__ tw,
@@ -141,18 +140,18 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
 // Same three passes, but the result stays in registers: on return lane t holds X[t + 256 d] in v[d]
 // (d = 0..15) -- which is exactly the layout pass 1 expects, so transforms can be chained
 // (FFT -> pointwise product -> inverse FFT) without touching LDS or HBM in between.
-template <int SIGN>
+template <int SIGN, bool TWP = true>
 __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
                                                        const float2 *__restrict__ tw) {
     const unsigned t = threadIdx.x;
     dft16<SIGN>(v);
     {
         float2 w[16];
-        twiddle_powers(w, tw, t, 4095u);
+        if (TWP) twiddle_powers(w, tw, t, 4095u);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float2 z = v[dft16_pos(c)];
-            if (c) z = cmul(z, w[c]);
+            if (c) z = cmul(z, TWP ? w[c] : tw[(unsigned)(t * c)]);
             lds[c * kEx1Stride + t] = z;
         }
     }
@@ -164,11 +163,11 @@ __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *
         __syncthreads();
         dft16<SIGN>(v);
         float2 wt[16];
-        twiddle_powers(wt, tw, 16 * bp, 4095u);
+        if (TWP) twiddle_powers(wt, tw, 16 * bp, 4095u);
 #pragma unroll
         for (int cp = 0; cp < 16; ++cp) {
             float2 u = v[dft16_pos(cp)];
-            if (cp) u = cmul(u, wt[cp]);
+            if (cp) u = cmul(u, TWP ? wt[cp] : tw[(unsigned)(16 * bp * cp)]);
             lds[bp * kEx2Stride + cp * 16 + c] = u;
         }
     }

@@ -19,6 +19,9 @@
 
 namespace yagi {
 
+#ifndef YG_FUSED_TWP
+#define YG_FUSED_TWP true       // twiddles by products also in the fused kernels (at 4 waves/SIMD: 0.174 -> 0.167 ms)
+#endif
 constexpr int kTile = 4096;                 // outputs per workgroup (= FFT length when fused)
 constexpr int kRowPad = 17;                 // 16 samples + 1 pad
 
@@ -166,7 +169,7 @@ firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__re
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = fl[padded(256 * a + threadIdx.x)];
         __syncthreads();
-        fft4096_passes<-1, false, false>(v, fl, tw, spectra + f * kTile);
+        fft4096_passes<-1, false, YG_FUSED_TWP>(v, fl, tw, spectra + f * kTile);
     }
 }
 
@@ -300,7 +303,7 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
                 for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
             }
             __syncthreads();
-            fft4096_passes<-1, (NW > 4), false>(v, xs, tw, out + o0);
+            fft4096_passes<-1, (NW > 4), YG_FUSED_TWP>(v, xs, tw, out + o0);
         } else {
             const int nt = (int)((n_units - o0) < (size_t)kTile ? (n_units - o0) : (size_t)kTile);
 #ifndef YG_ABL_NOSTORE
@@ -413,7 +416,10 @@ firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__rest
             }
         }
         // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
-        fft4096_passes_to_regs<-1>(v, lds, twf);
+#ifndef YG_CONV_TWP
+#define YG_CONV_TWP true
+#endif
+        fft4096_passes_to_regs<-1, YG_CONV_TWP>(v, lds, twf);
 #ifdef YG_CONV_FENCE
         __builtin_amdgcn_sched_barrier(0);      // keep the 16 hs loads below the forward transform
 #endif
@@ -422,7 +428,7 @@ firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__rest
             const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
             v[d] = make_float2(p.x * sc, p.y * sc);
         }
-        fft4096_passes_to_regs<+1>(v, lds, twb);
+        fft4096_passes_to_regs<+1, YG_CONV_TWP>(v, lds, twb);
         // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
         const size_t o0 = b * (size_t)V;
         if (INTERIOR) {
