@@ -218,7 +218,7 @@ def main():
             parity = f"unavailable: {e}"
 
     kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",
-                   3: "firfilt_crcf_fftconv_kernel<true> + fft4096_kernel<-1> (two launches per step)"}[eff_variant]
+                   3: "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (two launches per step)"}[eff_variant]
     # algorithmic bytes per input sample: fused = 8 in + 8 out; the two-kernel fast-convolution form also
     # writes and re-reads the FIR output stream ("32 if run as two kernels -- state which")
     bytes_per_sample = 32 if eff_variant == 3 else BYTES_PER_SAMPLE

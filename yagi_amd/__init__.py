@@ -198,7 +198,7 @@ class _Handle:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:                 # lib is None while the interpreter shuts down
             self._fn("destroy")(h)
             self._h = None
 

@@ -379,73 +379,57 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
 // ---------------------------------------------------------------------------------------------
 // x[-pre .. x_avail) is readable (pre = samples of the same stream stored in front of x[0], used when a
 // long block is processed in chunks); older samples come from `win` (the L-sample filter window).
-// INTERIOR = every block of the launch lies inside x (no window, no end-of-stream checks): the common
-// case gets a branch-free instance that needs no AGPR spill space (256 VGPRs -> 2 waves/SIMD instead of
-// 1: 0.129 -> 0.088 ms); the few boundary blocks go to the general instance in their own small launches.
-// (One launch with LDS-staged boundary blocks measured slower: 0.094 ms, profiles/r01_notes.md.)
-#ifndef YG_CONV_WAVES
-#define YG_CONV_WAVES 2
-#endif
-template <bool INTERIOR>
-__global__ void __launch_bounds__(256, INTERIOR ? YG_CONV_WAVES : 1)
+// One block per workgroup, one launch for all blocks.  Interior blocks (everything inside x) load straight
+// into registers; the few boundary blocks (stream start / end) take a block-uniform branch that stages the
+// block through the LDS buffer with per-sample checks.  (Boundary blocks in their own 1-block launches cost
+// ~9 us each, 13 % of a step.)  No grid-stride loop: inside one, the twiddle and FFT{h} loads are
+// loop-invariant and LICM keeps all 48 of them live across both transforms (256 VGPRs + spills vs 104).
+__global__ void __launch_bounds__(256)
 firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x, long long pre,
                             long long x_avail, const float2 *__restrict__ hs, float sc, int L, int V,
                             const float2 *__restrict__ twf, const float2 *__restrict__ twb,
-                            float2 *__restrict__ y, size_t ny, size_t b_first, size_t b_count) {
+                            float2 *__restrict__ y, size_t ny) {
     __shared__ float2 lds[kFft4096LdsFloat2];
-    // exactly one block per workgroup and NO grid-stride loop: inside a loop the twiddle and FFT{h} loads
-    // are loop-invariant, LICM hoists all 48 of them to the prologue and they stay live (or spilled) across
-    // both transforms
-    {
-        const size_t b = b_first + blockIdx.x;
-        (void)b_count;
-        const long long base = (long long)b * V - (L - 1);
-        float2 v[16];
-        if (INTERIOR) {
-            const float2 *src = x + base;            // block-uniform base (SGPRs) + 32-bit lane offset
+    const size_t b = blockIdx.x;
+    const long long base = (long long)b * V - (L - 1);
+    const bool interior = base >= -pre && base + 4096 <= x_avail && (b + 1) * (size_t)V <= ny;
+    float2 v[16];
+    if (interior) {
+        const float2 *src = x + base;                // block-uniform base (SGPRs) + 32-bit lane offset
 #pragma unroll
-            for (unsigned a = 0; a < 16; ++a) v[a] = src[256u * a + threadIdx.x];
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const long long idx = base + 256 * a + threadIdx.x;
-                float2 s = make_float2(0.f, 0.f);
-                if (idx >= -pre) { if (idx < x_avail) s = x[idx]; }
-                else if (idx >= -(long long)L) s = win[L + idx];
-                v[a] = s;
-            }
+        for (unsigned a = 0; a < 16; ++a) v[a] = src[256u * a + threadIdx.x];
+    } else {
+        for (int i = threadIdx.x; i < 4096; i += 256) {
+            const long long idx = base + i;
+            float2 s = make_float2(0.f, 0.f);
+            if (idx >= -pre) { if (idx < x_avail) s = x[idx]; }
+            else if (idx >= -(long long)L) s = win[L + idx];
+            lds[i] = s;
         }
-        // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
+        __syncthreads();
+#pragma unroll
+        for (unsigned a = 0; a < 16; ++a) v[a] = lds[256u * a + threadIdx.x];
+        __syncthreads();
+    }
 #ifndef YG_CONV_TWP
 #define YG_CONV_TWP true
 #endif
-        fft4096_passes_to_regs<-1, YG_CONV_TWP>(v, lds, twf);
-#ifdef YG_CONV_FENCE
-        __builtin_amdgcn_sched_barrier(0);      // keep the 16 hs loads below the forward transform
-#endif
+    // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
+    fft4096_passes_to_regs<-1, YG_CONV_TWP>(v, lds, twf);
 #pragma unroll
-        for (unsigned d = 0; d < 16; ++d) {
-            const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
-            v[d] = make_float2(p.x * sc, p.y * sc);
-        }
-        fft4096_passes_to_regs<+1, YG_CONV_TWP>(v, lds, twb);
-        // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
-        const size_t o0 = b * (size_t)V;
-        if (INTERIOR) {
-            // yb[n] with n = t + 256 d >= L-1: block-uniform base, 32-bit lane offsets
-            float2 *yb = y + o0 - (size_t)(L - 1);
+    for (unsigned d = 0; d < 16; ++d) {
+        const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
+        v[d] = make_float2(p.x * sc, p.y * sc);
+    }
+    fft4096_passes_to_regs<+1, YG_CONV_TWP>(v, lds, twb);
+    // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
+    const size_t o0 = b * (size_t)V;
+    const size_t lim = interior ? (size_t)V : (ny > o0 ? ny - o0 : 0);     // outputs this block may write
+    float2 *yb = y + o0 - (size_t)(L - 1);           // yb[n], n = t + 256 d >= L-1
 #pragma unroll
-            for (unsigned d = 0; d < 16; ++d) {
-                const unsigned n = threadIdx.x + 256u * d;
-                if (n >= (unsigned)(L - 1)) yb[n] = v[d];
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                const int n = (int)threadIdx.x + 256 * d - (L - 1);
-                if (n >= 0 && o0 + n < ny) y[o0 + n] = v[d];
-            }
-        }
+    for (unsigned d = 0; d < 16; ++d) {
+        const unsigned n = threadIdx.x + 256u * d;
+        if (n >= (unsigned)(L - 1) && (size_t)(n - (unsigned)(L - 1)) < lim) yb[n] = v[d];
     }
 }
 
@@ -456,33 +440,13 @@ int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x
     if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
     const int V = 4096 - (L - 1);
     const size_t nblk = (ny + V - 1) / V;
-    // interior blocks: base >= -pre, base + 4096 <= x_avail, and the whole valid part lies inside y
-    size_t b_lo = 0;
-    while (b_lo < nblk && (long long)b_lo * V - (L - 1) < -(long long)pre) ++b_lo;
-    size_t b_hi = nblk;
-    while (b_hi > b_lo && ((b_hi - 1) * (size_t)V + 4096 - (size_t)(L - 1) > x_avail || b_hi * (size_t)V > ny)) --b_hi;
-    const float2 *fw = reinterpret_cast<const float2 *>(win), *fx = reinterpret_cast<const float2 *>(x);
-    const float2 *fh = reinterpret_cast<const float2 *>(hs), *f1 = reinterpret_cast<const float2 *>(twf);
-    const float2 *f2 = reinterpret_cast<const float2 *>(twb);
-    float2 *fy = reinterpret_cast<float2 *>(y);
-    const float sc = scale / 4096.0f;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    auto grid_of = [](size_t n) { return (unsigned)n; };
-    if (b_lo > 0) {
-        firfilt_crcf_fftconv_kernel<false><<<grid_of(b_lo), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc, L, V,
-                                                                         f1, f2, fy, ny, 0, b_lo);
-        YG_LAUNCH_CHECK();
-    }
-    if (b_hi > b_lo) {
-        firfilt_crcf_fftconv_kernel<true><<<grid_of(b_hi - b_lo), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc,
-                                                                                 L, V, f1, f2, fy, ny, b_lo, b_hi - b_lo);
-        YG_LAUNCH_CHECK();
-    }
-    if (nblk > b_hi) {
-        firfilt_crcf_fftconv_kernel<false><<<grid_of(nblk - b_hi), 256, 0, st>>>(fw, fx, (long long)pre, (long long)x_avail, fh, sc,
-                                                                                  L, V, f1, f2, fy, ny, b_hi, nblk - b_hi);
-        YG_LAUNCH_CHECK();
-    }
+    firfilt_crcf_fftconv_kernel<<<(unsigned)nblk, 256, 0, st>>>(
+        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), (long long)pre,
+        (long long)x_avail, reinterpret_cast<const float2 *>(hs), scale / 4096.0f, L, V,
+        reinterpret_cast<const float2 *>(twf), reinterpret_cast<const float2 *>(twb),
+        reinterpret_cast<float2 *>(y), ny);
+    YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
