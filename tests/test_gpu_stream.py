@@ -26,7 +26,8 @@ def test_stream_small_vs_oracle(ya, oracle, L):
     h = (rng.standard_normal(L) / np.sqrt(L)).astype(np.float32)
     x = oracle.gen_complex(SEED + 2, 12 * 4096)
     truth = spectra_truth(oracle, h, 0.4, x)
-    for variant in ((1, 2, 3) if L <= 256 else (1, 3)):     # 1 sliding VALU FIR, 2 MFMA Toeplitz FIR, 3 fast convolution
+    # 1 sliding VALU FIR, 2 MFMA Toeplitz FIR, 3 fast convolution + FFT, 4 frequency-domain filter; 0 = auto
+    for variant in ((1, 2, 3, 4, 0) if L <= 256 else (1, 3, 4, 0) if L <= 257 else (1, 3, 0)):
         q = ya.FirFftStream(h)
         q.set_scale(0.4)
         q.set_variant(variant)
@@ -65,7 +66,7 @@ def test_stream_integer_alignment_exact(ya):
     x[4096 - 100] = 1.0          # its 256-sample response straddles the frame 0 / frame 1 boundary
     y = np.zeros(3 * 4096)
     y[4096 - 100: 4096 - 100 + 256] = 1.0
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         q = ya.FirFftStream(h)
         q.set_variant(variant)
         got = q.execute(x)
@@ -87,8 +88,8 @@ def test_headline_config_full_block(ya, oracle):
     q.set_scale(0.4)
     q.execute_dev(dx, nframes, dy)
     ya.synchronize()
-    # the other FIR forms (MFMA Toeplitz, fast convolution) give the same spectra
-    for variant in (2, 3):
+    # the time-domain forms (sliding, MFMA Toeplitz, fast convolution) give the same spectra as the default
+    for variant in (1, 2, 3):
         q2 = ya.FirFftStream(h)
         q2.set_scale(0.4)
         q2.set_variant(variant)

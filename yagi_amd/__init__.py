@@ -147,7 +147,7 @@ class DeviceArray:
         _check(lib.yagi_hip_memset_dev(self.ptr, 0, self.n * self.dtype.itemsize))
 
     def free(self):
-        if getattr(self, "ptr", None):
+        if getattr(self, "ptr", None) and lib is not None:        # lib is None while the interpreter shuts down
             lib.yagi_hip_free(self.ptr)
             self.ptr = None
 

@@ -72,6 +72,9 @@ struct DevWindow {
         return YAGI_OK;
     }
     const T *dev() const { return buf[cur].template as<T>(); }
+    // for kernels that write the next window themselves: the other buffer, then flip()
+    T *next() { return buf[1 - cur].template as<T>(); }
+    void flip() { cur = 1 - cur; }
     // window <- last len of (window ++ x_dev[0..n))
     int advance(const T *x_dev, size_t n, hipStream_t st) {
         if (n == 0) return YAGI_OK;
@@ -139,6 +142,7 @@ struct FirFilt {
     DevBuf apack;              // crcf only, L <= 256: Toeplitz A-operand table of the MFMA kernel
     int Lm = 0;                // padded length of the MFMA form (0 = not available)
     DevBuf hfreq, twf, twb;    // crcf only, L <= 2049: FFT_4096{[h;0]} and both twiddle tables (fast convolution)
+    DevBuf gcorr;              // crcf only, L <= 257: reversed taps of the frame-boundary correction (firfft variant 4)
     bool conv_ready = false;
     DevWindow<T> w;
     Workspace ws;
@@ -326,18 +330,36 @@ int FirFilt<K>::prepare_conv() {
     if (K::id != 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs crcf and <= 2049 taps");
     YG_TRY(make_twiddles(4096, YAGI_FFT_FORWARD, twf));
     YG_TRY(make_twiddles(4096, YAGI_FFT_BACKWARD, twb));
-    std::vector<cf32> hp(4096, cf32{0.f, 0.f});
-    for (int i = 0; i < L; ++i) hp[i] = cf32{reinterpret_cast<const float *>(h.data())[i], 0.f};
-    DevBuf tmp;
-    YG_TRY(tmp.alloc(4096 * sizeof(cf32)));
-    YG_TRY(hfreq.alloc(4096 * sizeof(cf32)));
-    YG_TRY(upload(tmp.p, hp.data(), 4096 * sizeof(cf32), st));
-    FftPlanDev d;
-    d.n = 4096;
-    d.dir = YAGI_FFT_FORWARD;
-    d.tw = twf.as<cf32>();
-    YG_TRY(launch_fft_batch(d, tmp.as<cf32>(), hfreq.as<cf32>(), 1, st));
-    YG_HIP(hipStreamSynchronize(st));
+    // FFT_4096{[h; 0]} evaluated in double on the host (L x 4096 terms, once per tap set), rounded once
+    {
+        std::vector<double> cs(4096), sn(4096);
+        for (int m = 0; m < 4096; ++m) {
+            const double a = -2.0 * M_PI * (double)m / 4096.0;
+            cs[m] = std::cos(a);
+            sn[m] = std::sin(a);
+        }
+        const float *hf = reinterpret_cast<const float *>(h.data());
+        std::vector<cf32> hp(4096);
+        for (int k = 0; k < 4096; ++k) {
+            double re = 0.0, im = 0.0;
+            for (int i = 0; i < L; ++i) {
+                const int m = (int)(((long long)i * k) & 4095);
+                re += (double)hf[i] * cs[m];
+                im += (double)hf[i] * sn[m];
+            }
+            hp[k] = cf32{(float)re, (float)im};
+        }
+        YG_TRY(hfreq.alloc(4096 * sizeof(cf32)));
+        YG_TRY(upload(hfreq.p, hp.data(), 4096 * sizeof(cf32), st));
+        // reversed taps of the frame-boundary correction (stream_kernels.hip, firfft_crcf_4096_freq_kernel)
+        if (L <= 257) {
+            std::vector<float> g(256, 0.0f);
+            for (int j = 0; j < L - 1; ++j) g[j] = hf[L - 1 - j];
+            YG_TRY(gcorr.alloc(256 * sizeof(float)));
+            YG_TRY(upload(gcorr.p, g.data(), 256 * sizeof(float), st));
+        }
+        YG_HIP(hipStreamSynchronize(st));      // the host vectors go out of scope
+    }
     conv_ready = true;
     return YAGI_OK;
 }
@@ -1557,8 +1579,9 @@ int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) { CHECK_
 int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->fir.w.reset(q->fir.st); }
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     CHECK_Q(q);
-    if (variant < 0 || variant > 3) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
-    if (variant >= 3 && q->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
+    if (variant < 0 || variant > 4) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    if (variant == 3 && q->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
+    if (variant == 4 && q->fir.L > 257) return fail(YAGI_ERR_CONFIG, "frequency-domain variant needs <= 257 taps");
     if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
     q->variant = variant;
     return YAGI_OK;
@@ -1572,7 +1595,16 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     YG_TRY(f.w.flush(f.st));
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
     // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
-    const bool use_conv = q->variant == 3 || (q->variant == 0 && f.L >= 96 && f.L <= 2049);
+    const bool use_freq = q->variant == 4 || (q->variant == 0 && f.L <= 257);
+    if (use_freq) {
+        // frequency-domain form (one kernel, 16 B/sample): FFT{h}.FFT{x_f} + FFT{frame-boundary correction}
+        YG_TRY(f.prepare_conv());
+        YG_TRY(launch_firfft_crcf_4096_freq(f.w.dev(), x, f.hfreq.as<cf32>(), f.gcorr.as<float>(), f.scale, f.L,
+                                            q->tw.as<cf32>(), spectra, f.w.next(), nframes, f.st));
+        f.w.flip();
+        return YAGI_OK;
+    }
+    const bool use_conv = q->variant == 3 || (q->variant == 0 && f.L <= 2049);
     if (use_conv) {
         // fast-convolution form (two kernels): overlap-save FIR into a scratch stream, then the batched
         // 4096-point FFT over its frames.  32 B/sample of HBM traffic instead of 16.  (Running the two

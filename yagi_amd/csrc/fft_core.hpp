@@ -20,37 +20,42 @@ constexpr int kFft4096LdsFloat2 = 16 * 272;          // 34816 B
 constexpr int kEx1Stride = 272;
 constexpr int kEx2Stride = 257;
 
-template <int SIGN>
+// ROTC: input c is first multiplied by -+i (a W^{N/4} twiddle folded into the butterfly's first adds)
+template <int SIGN, bool ROTC = false>
 __device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d) {
-    const float2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = csub(b, d);
-    const float2 r = (SIGN < 0) ? mul_mi(d1) : mul_pi(d1);
+    float2 s0, d0;
+    if (ROTC) addsub_rot<SIGN>(a, c, s0, d0);
+    else { s0 = cadd(a, c); d0 = csub(a, c); }
+    const float2 s1 = cadd(b, d), d1 = csub(b, d);
     a = cadd(s0, s1);
     c = csub(s0, s1);
-    b = cadd(d0, r);
-    d = csub(d0, r);
+    addsub_rot<SIGN>(d0, d1, b, d);
 }
 
 template <int SIGN>
 __device__ __forceinline__ float2 w16(float c, float s) { return make_float2(c, SIGN < 0 ? -s : s); }
 
 // In-place 16-point DFT.  Input v[n]; output X[k] is left at v[4*(k&3) + (k>>2)].
+// 64 packed adds + 8 constant products (2 packed instructions each) = 80 VALU instructions.
 template <int SIGN>
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4<SIGN>(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
     const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r2 = 0.70710678118654752f;
     // v[4*k0 + n0] *= W16^{n0*k0}
-    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w16<SIGN>(c1, s1));        // m = 1
-    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], w16<SIGN>(r2, r2));        // m = 2
-    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w16<SIGN>(s1, c1));        // m = 3
-    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], w16<SIGN>(r2, r2));        // m = 2
-    v[4 * 2 + 2] = (SIGN < 0) ? mul_mi(v[4 * 2 + 2]) : mul_pi(v[4 * 2 + 2]);   // m = 4
-    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], w16<SIGN>(-r2, r2));       // m = 6
-    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w16<SIGN>(s1, c1));        // m = 3
-    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], w16<SIGN>(-r2, r2));       // m = 6
-    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], w16<SIGN>(-c1, -s1));      // m = 9
-#pragma unroll
-    for (int k0 = 0; k0 < 4; ++k0) dft4<SIGN>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
+    v[4 * 1 + 1] = cmul_k(v[4 * 1 + 1], w16<SIGN>(c1, s1));        // m = 1
+    v[4 * 2 + 1] = cmul_k(v[4 * 2 + 1], w16<SIGN>(r2, r2));        // m = 2
+    v[4 * 3 + 1] = cmul_k(v[4 * 3 + 1], w16<SIGN>(s1, c1));        // m = 3
+    v[4 * 1 + 2] = cmul_k(v[4 * 1 + 2], w16<SIGN>(r2, r2));        // m = 2
+    //  v[4 * 2 + 2] *= W16^4 = -+i: inside the k0 = 2 butterfly below (ROTC)
+    v[4 * 3 + 2] = cmul_k(v[4 * 3 + 2], w16<SIGN>(-r2, r2));       // m = 6
+    v[4 * 1 + 3] = cmul_k(v[4 * 1 + 3], w16<SIGN>(s1, c1));        // m = 3
+    v[4 * 2 + 3] = cmul_k(v[4 * 2 + 3], w16<SIGN>(-r2, r2));       // m = 6
+    v[4 * 3 + 3] = cmul_k(v[4 * 3 + 3], w16<SIGN>(-c1, -s1));      // m = 9
+    dft4<SIGN>(v[0], v[1], v[2], v[3]);
+    dft4<SIGN>(v[4], v[5], v[6], v[7]);
+    dft4<SIGN, true>(v[8], v[9], v[10], v[11]);
+    dft4<SIGN>(v[12], v[13], v[14], v[15]);
 }
 
 // position of output k inside v after dft16
@@ -137,25 +142,12 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
     __syncthreads();                           // LDS free for the caller's next transform
 }
 
-// Same three passes, but the result stays in registers: on return lane t holds X[t + 256 d] in v[d]
-// (d = 0..15) -- which is exactly the layout pass 1 expects, so transforms can be chained
-// (FFT -> pointwise product -> inverse FFT) without touching LDS or HBM in between.
+// Passes 2 and 3 with the result left in registers: exchange-1 data (pass-1 output, lds[c*272 + b])
+// has been stored and a __syncthreads() has followed.  On return lane t holds X[t + 256 d] in v[d].
 template <int SIGN, bool TWP = true>
-__device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
+__device__ __forceinline__ void fft4096_pass23_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
                                                        const float2 *__restrict__ tw) {
     const unsigned t = threadIdx.x;
-    dft16<SIGN>(v);
-    {
-        float2 w[16];
-        if (TWP) twiddle_powers(w, tw, t, 4095u);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float2 z = v[dft16_pos(c)];
-            if (c) z = cmul(z, TWP ? w[c] : tw[(unsigned)(t * c)]);
-            lds[c * kEx1Stride + t] = z;
-        }
-    }
-    __syncthreads();
     {
         const unsigned c = t >> 4, bp = t & 15;
 #pragma unroll
@@ -179,6 +171,46 @@ __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *
 #pragma unroll
     for (int d = 0; d < 16; ++d) v[d] = w[dft16_pos(d)];
     __syncthreads();
+}
+
+// Same three passes as fft4096_passes, but the result stays in registers: on return lane t holds
+// X[t + 256 d] in v[d] (d = 0..15) -- which is exactly the layout pass 1 expects, so transforms can be
+// chained (FFT -> pointwise product -> inverse FFT) without touching LDS or HBM in between.
+template <int SIGN, bool TWP = true>
+__device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
+                                                       const float2 *__restrict__ tw) {
+    const unsigned t = threadIdx.x;
+    dft16<SIGN>(v);
+    {
+        float2 w[16];
+        if (TWP) twiddle_powers(w, tw, t, 4095u);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul(z, TWP ? w[c] : tw[(unsigned)(t * c)]);
+            lds[c * kEx1Stride + t] = z;
+        }
+    }
+    __syncthreads();
+    fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
+}
+
+// Transform of a sequence that is zero from sample 256 on: lane t holds x[t] in x0 (x[256a + t] = 0 for
+// a >= 1), so the first 16-point butterfly degenerates to Z_c[t] = W4096^{tc} x[t] -- pass 1 is 15
+// twiddle products instead of a butterfly.  Output layout as fft4096_passes_to_regs.
+template <int SIGN, bool TWP = true>
+__device__ __forceinline__ void fft4096_head256_to_regs(float2 x0, float2 (&v)[16], float2 *__restrict__ lds,
+                                                        const float2 *__restrict__ tw) {
+    const unsigned t = threadIdx.x;
+    {
+        float2 w[16];
+        if (TWP) twiddle_powers(w, tw, t, 4095u);
+        lds[t] = x0;
+#pragma unroll
+        for (int c = 1; c < 16; ++c) lds[c * kEx1Stride + t] = cmul(x0, TWP ? w[c] : tw[(unsigned)(t * c)]);
+    }
+    __syncthreads();
+    fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
 }
 
 }  // namespace yagi

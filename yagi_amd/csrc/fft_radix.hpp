@@ -22,9 +22,9 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     const float r2 = 0.70710678118654752f;
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft2<SIGN>(v[n0], v[4 + n0]);      // v[4*k1 + n0]
-    v[5] = cmul(v[5], w16<SIGN>(r2, r2));                             // W8^1
+    v[5] = cmul_k(v[5], w16<SIGN>(r2, r2));                             // W8^1
     v[6] = (SIGN < 0) ? mul_mi(v[6]) : mul_pi(v[6]);                  // W8^2
-    v[7] = cmul(v[7], w16<SIGN>(-r2, r2));                            // W8^3
+    v[7] = cmul_k(v[7], w16<SIGN>(-r2, r2));                            // W8^3
     dft4<SIGN>(v[0], v[1], v[2], v[3]);                               // -> X[k1=0 + 2*k0] at v[k0]
     dft4<SIGN>(v[4], v[5], v[6], v[7]);                               // -> X[1 + 2*k0] at v[4 + k0]
     // reorder to natural: X[k] = v[4*(k&1) + (k>>1)]

@@ -67,6 +67,12 @@ int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x
                             float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
                             hipStream_t st);
 
+// frequency-domain form of the firfilt_crcf -> 4096-pt FFT stream (1 <= L <= 257): FFT{h}.FFT{x_f} + FFT{boundary
+// correction}; gcorr[j] = h[L-1-j] (j < L-1, zero-padded to 256 floats); win_next <- last L samples of x.
+int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs, const float *gcorr, float scale,
+                                 int L, const cf32 *tw4096, cf32 *spectra, cf32 *win_next, size_t nframes,
+                                 hipStream_t st);
+
 // ---- fft_kernels.hip -----------------------------------------------------------------------
 struct FftPlanDev {
     int n = 0;
