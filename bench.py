@@ -6,8 +6,11 @@
 One "step" = one pass of the hot path over one batch of synthetic input: a 2^24-sample block
 (4096 frames of 4096) of complex f32 through FirFilter<Complex32,f32>::execute_block semantics
 (kaiser(256, 0.2, 60 dB) taps, scale 0.4, state carried from step to step) with every
-4096-sample output frame transformed by a forward FFT -- the fused HIP kernel behind
-yagi_hip_firfft_crcf_execute_dev.  Inputs and outputs are resident in HBM (PCIe excluded).
+4096-sample output frame transformed by a forward FFT -- yagi_hip_firfft_crcf_execute_dev, by default
+its frequency-domain kernel (FFT{h}.FFT{x_f} + FFT{frame-boundary correction}: one launch, the stream
+crosses HBM once each way).  The same workload through the direct-form (MFMA Toeplitz FIR + FFT) and
+the overlap-save forms is timed beside it ("direct_form", "fast_convolution"), untimed w.r.t. `value`.
+Inputs and outputs are resident in HBM (PCIe excluded).
 
 Multi-GPU: the path shards into independent streams: each rank filters its
 own stream, no data-path collective => "scaling": "weak"; value = all ranks' samples / max time.
@@ -70,8 +73,9 @@ def main():
                          "(a cold MI355X runs the first ~50 launches up to 25 %% slower); 0 disables")
     ap.add_argument("--frames", type=int, default=BLOCK_FRAMES, help="frames of 4096 samples per step")
     ap.add_argument("--variant", type=int, default=0,
-                    help="0 auto (= 3 at 256 taps), 1 fused direct-form (sliding VALU FIR), 2 fused MFMA Toeplitz "
-                         "FIR, 3 fast convolution (overlap-save kernel + batched FFT, two launches)")
+                    help="0 auto (= 4 at 256 taps), 1 fused direct-form (sliding VALU FIR), 2 fused MFMA Toeplitz "
+                         "FIR, 3 fast convolution (overlap-save kernel + batched FFT, two launches), "
+                         "4 frequency-domain filter with frame-boundary correction (one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend for the barrier / max-over-ranks reduction (nccl = RCCL; "
@@ -108,7 +112,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    eff_variant = 3 if args.variant == 0 else args.variant       # library's auto choice at 256 taps
+    eff_variant = 4 if args.variant == 0 else args.variant       # library's auto choice at 256 taps
     nframes = args.frames
     n = nframes * NFFT
     h = ya.fir_design_kaiser(TAPS, 0.2, 60.0)        # FirFilter::new_kaiser(256, 0.2, 60, 0)
@@ -156,13 +160,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
-    # the same workload through the fused direct-form kernel (dotprod-style FIR), K steps, reported beside
-    # the headline so both algorithms are on record (untimed w.r.t. `value`)
-    direct = None
-    if eff_variant == 3:
+    # the same workload through the other algorithms, K steps each, reported beside the headline so all
+    # three are on record (untimed w.r.t. `value`)
+    def time_variant(v):
         qd = ya.FirFftStream(h, NFFT)
         qd.set_scale(scale)
-        qd.set_variant(2)                 # fused MFMA Toeplitz FIR + FFT: the faster of the two direct forms
+        qd.set_variant(v)
         qd.set_stream(stream.cuda_stream)
         yd = torch.empty(n, dtype=torch.complex64, device=dev)
         for _ in range(max(args.warmup, 5)):
@@ -174,11 +177,19 @@ def main():
             qd.execute_dev(x, nframes, yd)
         e1.record(stream)
         torch.cuda.synchronize()
-        d_ms = e0.elapsed_time(e1) / args.steps
+        del yd
+        return e0.elapsed_time(e1) / args.steps
+
+    direct = fastconv = None
+    if eff_variant == 4:
+        d_ms = time_variant(2)            # fused MFMA Toeplitz FIR + FFT: the faster of the two direct forms
         direct = {"value": round(n / d_ms / 1e3, 3), "unit": "Msamples/s per GPU", "ms_per_step": round(d_ms, 4),
                   "kernel": "fir_crcf_mfma_kernel<68, true> (fused direct-form MFMA Toeplitz FIR + FFT, 16 B/sample)",
                   "fp32_tflops": round(FLOP_PER_SAMPLE * n / (d_ms / 1e3) / 1e12, 2)}
-        del yd
+        c_ms = time_variant(3)
+        fastconv = {"value": round(n / c_ms / 1e3, 3), "unit": "Msamples/s per GPU", "ms_per_step": round(c_ms, 4),
+                    "kernel": "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (overlap-save FIR, then batched FFT; "
+                              "32 B/sample)"}
 
     # variant 3 launches two kernels per step; the roofline object is about the dominant one (the overlap-save
     # FIR kernel), so time that kernel alone on the same input through FirFilter's kernel choice 4
@@ -218,12 +229,15 @@ def main():
             parity = f"unavailable: {e}"
 
     kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",
-                   3: "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (two launches per step)"}[eff_variant]
+                   3: "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (two launches per step)",
+                   4: "firfft_crcf_4096_freq_kernel"}[eff_variant]
     # algorithmic bytes per input sample: fused = 8 in + 8 out; the two-kernel fast-convolution form also
     # writes and re-reads the FIR output stream ("32 if run as two kernels -- state which")
     bytes_per_sample = 32 if eff_variant == 3 else BYTES_PER_SAMPLE
     # executed flops per input sample: direct 4*L + FFT 60; fast convolution 2 FFTs per 3841 outputs + product + FFT
-    flop_per_sample = round(2 * 60 * 4096 / 3841 + 6 + 60) if eff_variant == 3 else FLOP_PER_SAMPLE
+    # frequency-domain form: one FFT (60) + 2/3 of one for the zero-padded correction (~42) + the triangular
+    # correction sum 4*(255*256/2)/4096 (32) + the FFT{h} product, scale and final add (10)
+    flop_per_sample = {3: round(2 * 60 * 4096 / 3841 + 6 + 60), 4: 144}.get(eff_variant, FLOP_PER_SAMPLE)
     traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/traffic.json)
     try:
         tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
@@ -260,8 +274,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "firfilt_crcf 256-tap (kaiser 0.2/60dB, scale 0.4) -> 4096-pt forward FFT, "
                                    "streaming complex f32 (BASELINE configs[1] feeding configs[2])",
-                       "algorithm": ("fast convolution (overlap-save, 4096-pt blocks) + batched FFT" if eff_variant == 3
-                                     else "fused direct-form FIR + FFT"),
+                       "algorithm": {3: "fast convolution (overlap-save, 4096-pt blocks) + batched FFT",
+                                     4: "frequency-domain filter: FFT{h}.FFT{frame} + FFT{frame-boundary correction}"
+                                     }.get(eff_variant, "fused direct-form FIR + FFT"),
                        "samples_per_step_per_gpu": n, "frames_per_step": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
                        "kernel": kernel_name, "variant": args.variant, "prewarm_ms": args.prewarm_ms},
@@ -275,14 +290,15 @@ def main():
                          "step": {"ms": round(kern_s * 1e3, 4), "algorithmic_bytes": bytes_per_sample * n,
                                   "achieved_GBps": round(bytes_per_sample * n / kern_s / 1e9, 2),
                                   "frac_of_hbm_peak": round(bytes_per_sample * n / kern_s / 1e9 / HBM_PEAK_GBS, 4)},
-                         "note": ("fast convolution: overlap-save FIR kernel + batched FFT, FIR output stream crosses HBM once"
-                                  if eff_variant == 3 else
-                                  "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32"),
+                         "note": {3: "fast convolution: overlap-save FIR kernel + batched FFT, FIR output stream crosses HBM once",
+                                  4: "one launch per step; the stream is read once and the spectra written once"
+                                  }.get(eff_variant, "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32"),
                          "fp32": {"achieved_tflops": round(flop_per_sample * n / kern_s / 1e12, 2),
                                   "peak_tflops": FP32_PEAK_TFLOPS, "flop_per_sample": flop_per_sample,
                                   "frac": round(flop_per_sample * n / kern_s / 1e12 / FP32_PEAK_TFLOPS, 4)}},
             "parity_rel_l2_vs_f64": parity,
             "direct_form": direct,
+            "fast_convolution": fastconv,
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle

@@ -18,8 +18,8 @@ ya.gen_complex_dev(0x59414749 + 2, n, out=x, stream=st.cuda_stream)
 h = ya.fir_design_kaiser(256, 0.2, 60.0)
 keep = []
 for w in what:
-    if w in ("fused", "fused2", "fused3"):
-        f = ya.FirFftStream(h); f.set_stream(st.cuda_stream); f.set_variant({"fused": 1, "fused2": 2, "fused3": 3}[w])
+    if w in ("fused", "fused2", "fused3", "fused4"):
+        f = ya.FirFftStream(h); f.set_stream(st.cuda_stream); f.set_variant({"fused": 1, "fused2": 2, "fused3": 3, "fused4": 4}[w])
         fn = lambda f=f: f.execute_dev(x, n // 4096, y)
     elif w in ("fir1", "fir2", "fir3", "fir4"):
         q = ya.FirFilter("crcf", h); q.set_kernel(int(w[3])); q.set_stream(st.cuda_stream)

@@ -528,9 +528,16 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     float2 v[16];
 #pragma unroll
     for (unsigned a = 0; a < 16; ++a) v[a] = xf[256u * a + t];
+    // LDS layout of d and of the partial sums: sample m at float2 index m + 2 (m >> 5).  A lane reads /
+    // writes 32 contiguous bytes (4 samples) as two 16-byte accesses, so consecutive lanes are 32 B apart
+    // and lanes l, l + 8 would share banks; the 16 B of padding after every 32 samples moves lanes 8..15
+    // of each group of 16 onto the banks lanes 0..7 leave free (SQ_LDS_BANK_CONFLICT: 51 % of the LDS
+    // cycles of the unpadded kernel).
+    auto pidx = [](unsigned m) { return m + ((m >> 5) << 1); };
+    constexpr unsigned kDLen = 544, kPartStride = 272;            // 512 + 32 and 256 + 16 float2
     {
-        lds[t] = (int)t < Lc ? make_float2(dp_.x - dq_.x, dp_.y - dq_.y) : make_float2(0.f, 0.f);
-        lds[256 + t] = make_float2(0.f, 0.f);
+        lds[pidx(t)] = (int)t < Lc ? make_float2(dp_.x - dq_.x, dp_.y - dq_.y) : make_float2(0.f, 0.f);
+        lds[pidx(256 + t)] = make_float2(0.f, 0.f);
         if (f == nframes - 1)                        // new filter window = last L samples of the call
             for (int i = t; i < L; i += 256) win_next[i] = xf[4096 - L + i];
     }
@@ -546,9 +553,10 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
 #else
         if (j0 < Lc) {
 #endif
-            const float4 *dp = reinterpret_cast<const float4 *>(lds + 4 * l + j0);     // 2 samples per float4
+            const unsigned m0 = 4 * l + j0;                      // first sample of the lane's window
             float2 D[8];
             {
+                const float4 *dp = reinterpret_cast<const float4 *>(lds + pidx(m0));
                 const float4 q0 = dp[0], q1 = dp[1];
                 D[0] = make_float2(q0.x, q0.y); D[1] = make_float2(q0.z, q0.w);
                 D[2] = make_float2(q1.x, q1.y); D[3] = make_float2(q1.z, q1.w);
@@ -556,7 +564,8 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
             const float *g = gcorr + j0;
 #pragma unroll 4
             for (int jj = 0; jj < 64; jj += 4) {
-                const float4 q0 = dp[jj / 2 + 2], q1 = dp[jj / 2 + 3];
+                const float4 *dp = reinterpret_cast<const float4 *>(lds + pidx(m0 + jj + 4));
+                const float4 q0 = dp[0], q1 = dp[1];
                 D[4] = make_float2(q0.x, q0.y); D[5] = make_float2(q0.z, q0.w);
                 D[6] = make_float2(q1.x, q1.y); D[7] = make_float2(q1.z, q1.w);
 #pragma unroll
@@ -572,14 +581,15 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
                 for (int r = 0; r < 4; ++r) D[r] = D[4 + r];
             }
         }
-        float4 *cp = reinterpret_cast<float4 *>(lds + 512 + 256 * w + 4 * l);
+        float4 *cp = reinterpret_cast<float4 *>(lds + kDLen + kPartStride * w + pidx(4 * l));
         cp[0] = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
         cp[1] = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
     }
     __syncthreads();
     float2 cv;
     {
-        const float2 p0 = lds[512 + t], p1 = lds[768 + t], p2 = lds[1024 + t], p3 = lds[1280 + t];
+        const float2 *cp = lds + kDLen + pidx(t);
+        const float2 p0 = cp[0], p1 = cp[kPartStride], p2 = cp[2 * kPartStride], p3 = cp[3 * kPartStride];
         cv = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) * scale, ((p0.y + p1.y) + (p2.y + p3.y)) * scale);
     }
     __syncthreads();
