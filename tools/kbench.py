@@ -29,7 +29,7 @@ for name, k in (("fir1", 1), ("fir2", 2), ("fir3", 3), ("fir4", 4)):
         q.set_kernel(k)
         q.set_stream(st.cuda_stream)
         cases[f"firfilt_crcf256 kernel{k}"] = (lambda q=q: q.execute_block_dev(x, n, y), 16 * n)
-for name, v in (("fused", 1), ("fused2", 2), ("fused3", 3)):
+for name, v in (("fused", 1), ("fused2", 2), ("fused3", 3), ("fused4", 4)):
     if name in what:
         f = ya.FirFftStream(h)
         f.set_stream(st.cuda_stream)

@@ -514,7 +514,11 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
                              const float2 *__restrict__ tw, float2 *__restrict__ out,
                              float2 *__restrict__ win_next, unsigned nframes) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFft4096LdsFloat2];
+#ifdef YG_ABL_SAMEFRAME
+    const unsigned t = threadIdx.x, f = blockIdx.x & 15; // ablation: everything from / to L2
+#else
     const unsigned t = threadIdx.x, f = blockIdx.x;
+#endif
     const int Lc = L - 1;
     const float2 *xf = x + (size_t)f * 4096;
     // the two short loads of the correction go first: their wait must not include the 16 frame loads,
@@ -528,13 +532,13 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     float2 v[16];
 #pragma unroll
     for (unsigned a = 0; a < 16; ++a) v[a] = xf[256u * a + t];
-    // LDS layout of d and of the partial sums: sample m at float2 index m + 2 (m >> 5).  A lane reads /
-    // writes 32 contiguous bytes (4 samples) as two 16-byte accesses, so consecutive lanes are 32 B apart
-    // and lanes l, l + 8 would share banks; the 16 B of padding after every 32 samples moves lanes 8..15
-    // of each group of 16 onto the banks lanes 0..7 leave free (SQ_LDS_BANK_CONFLICT: 51 % of the LDS
-    // cycles of the unpadded kernel).
-    auto pidx = [](unsigned m) { return m + ((m >> 5) << 1); };
-    constexpr unsigned kDLen = 544, kPartStride = 272;            // 512 + 32 and 256 + 16 float2
+    // LDS layout of d and of the partial sums: sample m at float2 index m + 2 (m >> 2), i.e. 16 B of padding
+    // after every 4 samples.  A lane reads / writes its 4 samples as two 16-byte accesses; with lanes 32 B
+    // apart every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) would hit each bank twice (measured:
+    // SQ_LDS_BANK_CONFLICT = 51 % of the kernel's LDS cycles), at 48 B apart the 16 lanes of a group cover
+    // the 64 banks exactly once for every window position.
+    auto pidx = [](unsigned m) { return m + ((m >> 2) << 1); };
+    constexpr unsigned kDLen = 768, kPartStride = 384;            // 1.5 x (512 and 256) float2
     {
         lds[pidx(t)] = (int)t < Lc ? make_float2(dp_.x - dq_.x, dp_.y - dq_.y) : make_float2(0.f, 0.f);
         lds[pidx(256 + t)] = make_float2(0.f, 0.f);
