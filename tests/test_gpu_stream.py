@@ -20,14 +20,14 @@ def spectra_truth(oracle, h, scale, x, nfft=4096):
     return np.array([np.fft.fft(y[f * nfft:(f + 1) * nfft]) for f in range(len(x) // nfft)])
 
 
-@pytest.mark.parametrize("L", [1, 4, 63, 256, 257, 1000])
+@pytest.mark.parametrize("L", [1, 2, 4, 63, 130, 256, 257, 1000, 2049])
 def test_stream_small_vs_oracle(ya, oracle, L):
     rng = np.random.default_rng(L)
     h = (rng.standard_normal(L) / np.sqrt(L)).astype(np.float32)
     x = oracle.gen_complex(SEED + 2, 12 * 4096)
     truth = spectra_truth(oracle, h, 0.4, x)
     # 1 sliding VALU FIR, 2 MFMA Toeplitz FIR, 3 fast convolution + FFT, 4 frequency-domain filter; 0 = auto
-    for variant in ((1, 2, 3, 4, 0) if L <= 256 else (1, 3, 4, 0) if L <= 257 else (1, 3, 0)):
+    for variant in ((1, 2, 3, 4, 0) if L <= 256 else (1, 3, 4, 0) if L <= 257 else (1, 3, 0) if L <= 1024 else (3, 0)):
         q = ya.FirFftStream(h)
         q.set_scale(0.4)
         q.set_variant(variant)
@@ -52,7 +52,7 @@ def test_stream_config(ya):
     with pytest.raises(ya.ConfigError):
         ya.FirFftStream(np.ones(8, np.float32), nfft=1024)
     with pytest.raises(ya.ConfigError):
-        ya.FirFftStream(np.ones(2000, np.float32))
+        ya.FirFftStream(np.ones(2050, np.float32))
     q = ya.FirFftStream(np.ones(8, np.float32))
     with pytest.raises(ya.ConfigError):
         q.execute(np.zeros(100, np.complex64))

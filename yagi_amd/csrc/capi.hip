@@ -1562,7 +1562,7 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
     if (nfft != 4096) return fail(YAGI_ERR_CONFIG, "fused stream supports nfft = 4096 (got %zu)", nfft);
     auto o = std::make_unique<yagi_hip_firfft_crcf_s>();
     YG_TRY(o->fir.init(h, h_len));
-    if (o->fir.Lp > kSlideMaxTaps) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%zu taps)", h_len);
+    if (o->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%zu taps, at most 2049)", h_len);
     o->nfft = nfft;
     YG_TRY(make_twiddles((int)nfft, YAGI_FFT_FORWARD, o->tw));
     *q = o.release();
@@ -1583,6 +1583,7 @@ int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     if (variant == 3 && q->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
     if (variant == 4 && q->fir.L > 257) return fail(YAGI_ERR_CONFIG, "frequency-domain variant needs <= 257 taps");
     if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
+    if (variant == 1 && q->fir.Lp > kSlideMaxTaps) return fail(YAGI_ERR_CONFIG, "sliding variant needs <= %d taps", kSlideMaxTaps);
     q->variant = variant;
     return YAGI_OK;
 }
