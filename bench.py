@@ -188,7 +188,7 @@ def main():
                   "fp32_tflops": round(FLOP_PER_SAMPLE * n / (d_ms / 1e3) / 1e12, 2)}
         c_ms = time_variant(3)
         fastconv = {"value": round(n / c_ms / 1e3, 3), "unit": "Msamples/s per GPU", "ms_per_step": round(c_ms, 4),
-                    "kernel": "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (overlap-save FIR, then batched FFT; "
+                    "kernel": "firfilt_fftconv_kernel<0> + fft4096_kernel<-1> (overlap-save FIR, then batched FFT; "
                               "32 B/sample)"}
 
     # variant 3 launches two kernels per step; the roofline object is about the dominant one (the overlap-save
@@ -229,7 +229,7 @@ def main():
             parity = f"unavailable: {e}"
 
     kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",
-                   3: "firfilt_crcf_fftconv_kernel + fft4096_kernel<-1> (two launches per step)",
+                   3: "firfilt_fftconv_kernel<0> + fft4096_kernel<-1> (two launches per step)",
                    4: "firfft_crcf_4096_freq_kernel"}[eff_variant]
     # algorithmic bytes per input sample: fused = 8 in + 8 out; the two-kernel fast-convolution form also
     # writes and re-reads the FIR output stream ("32 if run as two kernels -- state which")

@@ -265,10 +265,15 @@ YAGI_FIRINTERP_API(rrrf, float, float)
 YAGI_FIRINTERP_API(crcf, yagi_cf32, float)
 YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
 
-/* crcf only: which block kernel execute_block uses.  0 = auto, 1 = general LDS-broadcast kernel
- * (fir_kernels.hip), 2 = register-sliding kernel, 3 = MFMA Toeplitz kernel (<= 256 taps), 4 = fast
- * convolution (overlap-save, <= 2049 taps; f32-rounding agreement only) -- all in stream_kernels.hip. */
+/* Which kernel execute_block uses.  0 = auto (always a direct form), 1 = general direct-form kernel
+ * (fir_kernels.hip), 4 = overlap-save fast convolution (<= 2049 taps; stream_kernels.hip).
+ * crcf also: 2 = register-sliding direct form (<= 1024 taps), 3 = MFMA Toeplitz direct form (<= 256 taps).
+ * The direct forms evaluate the reference's sums (exact on integer-valued data); the fast convolution agrees
+ * with them to f32 rounding (rel. L2 <= 2e-6 against the f64 truth), like the reference's own FftFilt, and is
+ * 2.5x (crcf, 256 taps) to 10x (rrrf, cccf) faster on long blocks. */
+int yagi_hip_firfilt_rrrf_set_kernel(yagi_hip_firfilt_rrrf q, int choice);
 int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);
+int yagi_hip_firfilt_cccf_set_kernel(yagi_hip_firfilt_cccf q, int choice);
 
 /* ---- Fft<f32>: src/fft/mod.rs:33-69 (arithmetic = rustfft 6.2 in the reference) ------------
  *   create       Fft::new(n, direction)        :39-43   any n >= 1 the engine supports

@@ -145,28 +145,63 @@ def test_firfilt_crcf_mfma_kernel_lengths(ya, oracle, L):
     assert rel_l2(got, truth) <= 2e-6
 
 
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("L", [1, 2, 33, 256, 1000, 2049])
-def test_firfilt_crcf_fast_convolution_kernel(ya, oracle, L):
-    """kernel 4: overlap-save fast convolution (FFT -> product -> IFFT in registers).  Same tolerance as
-    the direct kernels vs the f64 truth; integer exactness is NOT claimed for it."""
+def test_firfilt_fast_convolution_kernel(ya, oracle, kind, L):
+    """kernel 4: overlap-save fast convolution (FFT -> product -> IFFT in registers; rrrf: two blocks per
+    transform; cccf: complex taps and scale).  Same tolerance as the direct kernels vs the f64 truth;
+    integer exactness is NOT claimed for it."""
     rng = np.random.default_rng(4000 + L)
-    h, x = rand_taps(rng, "crcf", L), rand_samples(rng, "crcf", 5 * 4096 + 123)
-    q = ya.FirFilter("crcf", h)
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, 5 * 4096 + 123)
+    scale = (0.75 - 0.5j) if kind == "cccf" else 0.75
+    q = ya.FirFilter(kind, h)
     q.set_kernel(4)
-    q.set_scale(0.75)
+    q.set_scale(scale)
     got = np.concatenate([q.execute_block(x[:7000]), q.execute_block(x[7000:7001]), q.execute_block(x[7001:])])
-    truth = oracle.fir_block_f64("crcf", h, x, scale=0.75)
-    assert np.max(np.abs(got - truth)) <= fir_bound("crcf", h, x)
+    truth = oracle.fir_block_f64(kind, h, x, scale=scale)
+    assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x) * abs(scale) / 0.75
     assert rel_l2(got, truth) <= 2e-6
     q.set_coefficients(h[::-1].copy())            # new taps -> the cached FFT{h} must be rebuilt
-    q.set_scale(0.75)
+    q.set_scale(scale)
     got = q.execute_block(x[:5000])
-    assert rel_l2(got, oracle.fir_block_f64("crcf", h[::-1], x[:5000], scale=0.75)) <= 2e-6
+    assert rel_l2(got, oracle.fir_block_f64(kind, h[::-1], x[:5000], scale=scale)) <= 2e-6
     if L > 2049 - 1:
         with pytest.raises(ya.ConfigError):
-            big = ya.FirFilter("crcf", rand_taps(rng, "crcf", 2050))
+            big = ya.FirFilter(kind, rand_taps(rng, kind, 2050))
             big.set_kernel(4)
             big.execute_block(x[:4096])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firfilt_kernel_switch_keeps_state(ya, oracle, kind):
+    """one stream, kernel switched between calls (overlap-save for the long block, direct form for the rest):
+    state carried across the switch, odd number of convolution blocks (rrrf pairs them), output not a multiple
+    of the block length; the auto choice is the direct form"""
+    rng = np.random.default_rng(77)
+    L, n = 129, 8 * 3968 + 1234
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n + 3000)
+    truth = oracle.fir_block_f64(kind, h, x)
+    q = ya.FirFilter(kind, h)
+    q.set_kernel(4)
+    a = q.execute_block(x[:n])
+    q.set_kernel(0)
+    got = np.concatenate([a, q.execute_block(x[n:n + 1000]), q.execute_block(x[n + 1000:])])
+    assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x)
+    assert rel_l2(got, truth) <= 2e-6
+    d = ya.FirFilter(kind, h)
+    direct = d.execute_block(x)                             # auto
+    d1 = ya.FirFilter(kind, h)
+    d1.set_kernel(1)
+    if kind != "crcf":
+        assert np.array_equal(direct, d1.execute_block(x))  # auto == general direct form
+    assert rel_l2(got, direct) <= 2e-6
+    assert not np.array_equal(got[:n], direct[:n])          # the long block really took the other kernel
+    assert rel_l2(got[n:], direct[n:]) <= 1e-6
+    with pytest.raises(ya.ConfigError):
+        q.set_kernel(7)
+    if kind != "crcf":
+        with pytest.raises(ya.ConfigError):
+            q.set_kernel(2)
 
 
 def test_config_c1_firfilt_rrrf_63tap_1M(ya, oracle):

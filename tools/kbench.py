@@ -35,6 +35,21 @@ for name, v in (("fused", 1), ("fused2", 2), ("fused3", 3), ("fused4", 4)):
         f.set_stream(st.cuda_stream)
         f.set_variant(v)
         cases[f"fused fir256+fft4096 v{v}"] = (lambda f=f: f.execute_dev(x, n // 4096, y), 16 * n)
+if "rrrf" in what:      # C1 filter at GPU block size: 63-tap real FIR over 2^24 real samples
+    hr = ya.fir_design_kaiser(63, 0.2, 60.0)
+    qr = ya.FirFilter("rrrf", hr)
+    qr.set_stream(st.cuda_stream)
+    xr = x.view(torch.float32)
+    yr = y.view(torch.float32)
+    cases["firfilt_rrrf 63-tap"] = (lambda: qr.execute_block_dev(xr, n, yr), 8 * n)
+    qr2 = ya.FirFilter("rrrf", h)
+    qr2.set_stream(st.cuda_stream)
+    cases["firfilt_rrrf 256-tap"] = (lambda: qr2.execute_block_dev(xr, n, yr), 8 * n)
+if "cccf" in what:
+    hc = (h * np.exp(0.3j * np.arange(h.size))).astype(np.complex64)
+    qc = ya.FirFilter("cccf", hc)
+    qc.set_stream(st.cuda_stream)
+    cases["firfilt_cccf 256-tap"] = (lambda: qc.execute_block_dev(x, n, y), 16 * n)
 if "chan1" in what:
     c1 = ya.FirPfbCh.new_kaiser(64, 8, 60.0)
     c1.set_stream(st.cuda_stream)

@@ -309,10 +309,9 @@ class FirFilter(_FirBase):
         return h
 
     def set_kernel(self, choice):
-        """crcf only: 0 auto, 1 general kernel, 2 register-sliding kernel."""
-        if self.kind != "crcf":
-            raise ConfigError("kernel choice exists for crcf only")
-        _check(lib.yagi_hip_firfilt_crcf_set_kernel(self._h, choice))
+        """0 auto, 1 general direct form, 4 overlap-save fast convolution; crcf also 2 register-sliding and
+        3 MFMA Toeplitz direct forms (include/yagi_hip.h)."""
+        _check(self._fn("set_kernel")(self._h, choice))
 
 
 class FirDecimationFilter(_FirBase):

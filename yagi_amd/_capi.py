@@ -151,7 +151,8 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute_blocks", vp, vp, sz, vp)
     _sig(p + "execute_blocks_dev", vp, vp, sz, vp)
 
-_sig("yagi_hip_firfilt_crcf_set_kernel", vp, ci)
+for _k in ("rrrf", "crcf", "cccf"):
+    _sig(f"yagi_hip_firfilt_{_k}_set_kernel", vp, ci)
 
 for _k, _T in (("cf", cf32), ("f", f32)):
     p = f"yagi_hip_spgram{_k}_"

@@ -14,6 +14,8 @@
 //     roofline that bounds a direct-form 256-tap crcf filter on MI355X (64 flop/B).
 // Algorithmic HBM traffic: 8 B read + 8 B written per sample (16 B/sample) in both kernels; in
 // the fused kernel the FIR output goes registers -> LDS -> FFT registers and never touches HBM.
+#include <type_traits>
+
 #include "fft_core.hpp"
 #include "kernels.hpp"
 
@@ -374,37 +376,64 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
 //   inverse FFT -> the last V time samples are y[V*b .. V*b + V).
 // 2 x 245 760 flop per 4096-V.. block instead of 4*L flop per sample: ~134 flop/sample at L = 256, so the
 // kernel is bound by HBM/LDS, not FP32.  Traffic: 8*(4096/V) B read + 8 B written per sample.
-// Results agree with the direct form to f32 rounding (rel 1e-6) but are NOT exact for integer inputs,
-// so this is an opt-in kernel choice, not FirFilter's default.
+// Results agree with the direct form to f32 rounding (rel 1e-6) but are NOT exact for integer inputs:
+// FirFilter picks it only for long blocks (capi.hip), never for the per-sample / short-block calls.
+//
+// All three type combinations run on it (KIND):
+//   crcf  complex samples, real taps, real scale
+//   cccf  complex samples, complex taps (FFT{h} is simply not conjugate-symmetric), complex scale
+//   rrrf  real samples: TWO consecutive blocks ride one complex transform as its real and imaginary parts
+//         (h real => IFFT(H FFT(a + ib)) = h*a + i h*b), so a workgroup produces 2V real outputs
 // ---------------------------------------------------------------------------------------------
 // x[-pre .. x_avail) is readable (pre = samples of the same stream stored in front of x[0], used when a
 // long block is processed in chunks); older samples come from `win` (the L-sample filter window).
-// One block per workgroup, one launch for all blocks.  Interior blocks (everything inside x) load straight
-// into registers; the few boundary blocks (stream start / end) take a block-uniform branch that stages the
-// block through the LDS buffer with per-sample checks.  (Boundary blocks in their own 1-block launches cost
-// ~9 us each, 13 % of a step.)  No grid-stride loop: inside one, the twiddle and FFT{h} loads are
-// loop-invariant and LICM keeps all 48 of them live across both transforms (256 VGPRs + spills vs 104).
+// One block (rrrf: pair of blocks) per workgroup, one launch for all blocks.  Interior blocks (everything
+// inside x) load straight into registers; the few boundary blocks (stream start / end) take a block-uniform
+// branch that stages the block through the LDS buffer with per-sample checks.  (Boundary blocks in their own
+// 1-block launches cost ~9 us each, 13 % of a step.)  No grid-stride loop: inside one, the twiddle and FFT{h}
+// loads are loop-invariant and LICM keeps all 48 of them live across both transforms (256 VGPRs + spills
+// vs 104).
+enum { kConvCrcf = 0, kConvRrrf = 1, kConvCccf = 2 };
+
+template <class T>
+__device__ __forceinline__ T conv_fetch(const T *__restrict__ win, const T *__restrict__ x, long long idx,
+                                        long long pre, long long x_avail, int L) {
+    T s{};
+    if (idx >= -pre) { if (idx < x_avail) s = x[idx]; }
+    else if (idx >= -(long long)L) s = win[L + idx];
+    return s;
+}
+
+template <int KIND>
 __global__ void __launch_bounds__(256)
-firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x, long long pre,
-                            long long x_avail, const float2 *__restrict__ hs, float sc, int L, int V,
-                            const float2 *__restrict__ twf, const float2 *__restrict__ twb,
-                            float2 *__restrict__ y, size_t ny) {
+firfilt_fftconv_kernel(const void *__restrict__ win_, const void *__restrict__ x_, long long pre,
+                       long long x_avail, const float2 *__restrict__ hs, float2 sc, int L, int V,
+                       const float2 *__restrict__ twf, const float2 *__restrict__ twb,
+                       void *__restrict__ y_, size_t ny) {
+    constexpr bool REAL = KIND == kConvRrrf;
+    using T = typename std::conditional<REAL, float, float2>::type;
+    const T *win = static_cast<const T *>(win_), *x = static_cast<const T *>(x_);
+    T *y = static_cast<T *>(y_);
     __shared__ float2 lds[kFft4096LdsFloat2];
-    const size_t b = blockIdx.x;
-    const long long base = (long long)b * V - (L - 1);
-    const bool interior = base >= -pre && base + 4096 <= x_avail && (b + 1) * (size_t)V <= ny;
+    const size_t k0 = (REAL ? 2 : 1) * (size_t)blockIdx.x;            // first conv block of this workgroup
+    const long long base = (long long)k0 * V - (L - 1);
+    const long long last = base + (REAL ? V : 0) + 4096;              // end of the (second) block's input
+    const bool interior = base >= -pre && last <= x_avail && (k0 + (REAL ? 2 : 1)) * (size_t)V <= ny;
     float2 v[16];
     if (interior) {
-        const float2 *src = x + base;                // block-uniform base (SGPRs) + 32-bit lane offset
+        const T *src = x + base;                     // block-uniform base (SGPRs) + 32-bit lane offset
 #pragma unroll
-        for (unsigned a = 0; a < 16; ++a) v[a] = src[256u * a + threadIdx.x];
+        for (unsigned a = 0; a < 16; ++a) {
+            if constexpr (REAL) v[a] = make_float2(src[256u * a + threadIdx.x], src[V + 256u * a + threadIdx.x]);
+            else v[a] = src[256u * a + threadIdx.x];
+        }
     } else {
         for (int i = threadIdx.x; i < 4096; i += 256) {
-            const long long idx = base + i;
-            float2 s = make_float2(0.f, 0.f);
-            if (idx >= -pre) { if (idx < x_avail) s = x[idx]; }
-            else if (idx >= -(long long)L) s = win[L + idx];
-            lds[i] = s;
+            if constexpr (REAL)
+                lds[i] = make_float2(conv_fetch(win, x, base + i, pre, x_avail, L),
+                                     conv_fetch(win, x, base + V + i, pre, x_avail, L));
+            else
+                lds[i] = conv_fetch(win, x, base + i, pre, x_avail, L);
         }
         __syncthreads();
 #pragma unroll
@@ -419,35 +448,60 @@ firfilt_crcf_fftconv_kernel(const float2 *__restrict__ win, const float2 *__rest
 #pragma unroll
     for (unsigned d = 0; d < 16; ++d) {
         const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
-        v[d] = make_float2(p.x * sc, p.y * sc);
+        if constexpr (KIND == kConvCccf) v[d] = cmul(p, sc);
+        else v[d] = cscale(p, sc.x);
     }
     fft4096_passes_to_regs<+1, YG_CONV_TWP>(v, lds, twb);
-    // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*b + n - (L-1)]
-    const size_t o0 = b * (size_t)V;
-    const size_t lim = interior ? (size_t)V : (ny > o0 ? ny - o0 : 0);     // outputs this block may write
-    float2 *yb = y + o0 - (size_t)(L - 1);           // yb[n], n = t + 256 d >= L-1
+    // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*k + n - (L-1)]
+    const size_t o0 = k0 * (size_t)V;
+    const size_t left = ny > o0 ? ny - o0 : 0;                         // outputs from o0 to the end of y
+    const size_t lim0 = interior ? (size_t)V : (left < (size_t)V ? left : (size_t)V);
+    T *yb = y + o0 - (size_t)(L - 1);                // yb[n], n = t + 256 d >= L-1
 #pragma unroll
     for (unsigned d = 0; d < 16; ++d) {
         const unsigned n = threadIdx.x + 256u * d;
-        if (n >= (unsigned)(L - 1) && (size_t)(n - (unsigned)(L - 1)) < lim) yb[n] = v[d];
+        if (n < (unsigned)(L - 1)) continue;
+        const size_t j = n - (unsigned)(L - 1);
+        if constexpr (REAL) {
+            if (j < lim0) yb[n] = v[d].x;
+            if (interior || j + (size_t)V < left) yb[(size_t)V + n] = v[d].y;
+        } else {
+            if (j < lim0) yb[n] = v[d];
+        }
     }
+}
+
+template <int KIND, class T>
+static int launch_fir_fftconv_t(const T *win, const T *x, size_t pre, size_t x_avail, const cf32 *hs, cf32 scale,
+                                int L, const cf32 *twf, const cf32 *twb, T *y, size_t ny, hipStream_t st) {
+    if (ny == 0) return YAGI_OK;
+    if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
+    const int V = 4096 - (L - 1);
+    const size_t nblk = (ny + V - 1) / V;
+    const size_t nwg = KIND == kConvRrrf ? (nblk + 1) / 2 : nblk;
+    if (nwg > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    firfilt_fftconv_kernel<KIND><<<(unsigned)nwg, 256, 0, st>>>(
+        win, x, (long long)pre, (long long)x_avail, reinterpret_cast<const float2 *>(hs),
+        make_float2(scale.re / 4096.0f, scale.im / 4096.0f), L, V, reinterpret_cast<const float2 *>(twf),
+        reinterpret_cast<const float2 *>(twb), y, ny);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
 }
 
 int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
                             float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
                             hipStream_t st) {
-    if (ny == 0) return YAGI_OK;
-    if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
-    const int V = 4096 - (L - 1);
-    const size_t nblk = (ny + V - 1) / V;
-    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    firfilt_crcf_fftconv_kernel<<<(unsigned)nblk, 256, 0, st>>>(
-        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), (long long)pre,
-        (long long)x_avail, reinterpret_cast<const float2 *>(hs), scale / 4096.0f, L, V,
-        reinterpret_cast<const float2 *>(twf), reinterpret_cast<const float2 *>(twb),
-        reinterpret_cast<float2 *>(y), ny);
-    YG_LAUNCH_CHECK();
-    return YAGI_OK;
+    return launch_fir_fftconv_t<kConvCrcf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st);
+}
+int launch_fir_cccf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
+                            cf32 scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
+                            hipStream_t st) {
+    return launch_fir_fftconv_t<kConvCccf>(win, x, pre, x_avail, hs, scale, L, twf, twb, y, ny, st);
+}
+int launch_fir_rrrf_fftconv(const float *win, const float *x, size_t pre, size_t x_avail, const cf32 *hs,
+                            float scale, int L, const cf32 *twf, const cf32 *twb, float *y, size_t ny,
+                            hipStream_t st) {
+    return launch_fir_fftconv_t<kConvRrrf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st);
 }
 
 // M = 1 crcf block FIR with the sliding kernel; taps_pad = h zero-padded to Lp = roundup(L, 32)
