@@ -157,10 +157,12 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
                     const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
                     float2 *__restrict__ y, size_t nframes, int run) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 frames][M]
-    float2 *vb = va + 256 * kColHalf;
-    float2 *twl = vb + 256 * kColHalf;                          // M
     const int G = 256 / M;
+    const int nq = G * kColHalf, lgnq = 31 - __builtin_clz((unsigned)nq);      // transforms per half tile
+    const int pitch = frfast_pitch(M, nq);
+    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 frames][pitch]
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;                              // M
     const int lgM = 31 - __builtin_clz((unsigned)M);
     const int g = threadIdx.x >> lgM, c = threadIdx.x & (M - 1);
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
@@ -200,15 +202,15 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * M + c] = acc[half * kColHalf + j];
+                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * pitch + c] = acc[half * kColHalf + j];
                 __syncthreads();
-                float2 *res = lds_fft_pow2<-1>(va, vb, M, G * kColHalf, plan, twl, 1);
+                float2 *res = lds_fft_pow2<-1, true>(va, vb, M, nq, plan, twl, 1, true, pitch, lgnq);
                 // transform q = g'*8 + j is frame f_begin(g') + t0 + 8*half + j
                 for (int e = threadIdx.x; e < 256 * kColHalf; e += 256) {
                     const int q = e >> lgM, k = e & (M - 1);
                     const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
                     const long long f = (long long)(gblk * G + gq) * run + t0 + j;
-                    if (t0 + j < run && f < (long long)nframes) y[f * M + k] = res[e];
+                    if (t0 + j < run && f < (long long)nframes) y[f * M + k] = res[q * pitch + k];
                 }
                 __syncthreads();
             }
@@ -229,7 +231,7 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const size_t ngroups = (nframes + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
     const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
-    const size_t lds = (2 * 256 * (size_t)kColHalf + (size_t)M) * sizeof(float2);
+    const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
         YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P>),
@@ -384,10 +386,12 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                      const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
                      int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, even */) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][M]
-    float2 *vb = va + 256 * kColHalf;
-    float2 *twl = vb + 256 * kColHalf;                          // M
     const int G = 256 / M, M2 = M / 2, Mr = M / R;
+    const int nq = G * kColHalf, lgnq = 31 - __builtin_clz((unsigned)nq);      // transforms in flight
+    const int pitch = frfast_pitch(M, nq);
+    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][pitch]
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;                              // M
     const int lgM = 31 - __builtin_clz((unsigned)M), lgMr = 31 - __builtin_clz((unsigned)Mr);
     const int g = threadIdx.x >> lgM, b = threadIdx.x & (M - 1);
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
@@ -444,10 +448,9 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * M + b] = acc[half * kColHalf + j];
+                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * pitch + b] = acc[half * kColHalf + j];
                 __syncthreads();
                 float2 *srcb = va, *dstb = vb;
-                const int nq = G * kColHalf;                               // transforms in flight
                 if (R > 1) {
                     for (int e = threadIdx.x; e < nq * Mr; e += 256) {
                         const int q = e >> lgMr, bq = e & (Mr - 1);
@@ -455,23 +458,23 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                         for (int aa = 0; aa < R; ++aa) {
                             float2 wv = twl[((aa * rank) % R) * Mr];
                             wv.y = -wv.y;
-                            a = cadd(a, cmul(va[q * M + Mr * aa + bq], wv));
+                            a = cadd(a, cmul(va[q * pitch + Mr * aa + bq], wv));
                         }
                         float2 w2 = twl[(bq * rank) & (M - 1)];
                         w2.y = -w2.y;
-                        vb[e] = cmul(a, w2);
+                        vb[q * pitch + bq] = cmul(a, w2);
                     }
                     __syncthreads();
                     srcb = vb;
                     dstb = va;
                 }
-                float2 *res = lds_fft_pow2<+1>(srcb, dstb, Mr, nq, plan, twl, R);
+                float2 *res = lds_fft_pow2<+1, true>(srcb, dstb, Mr, nq, plan, twl, R, true, pitch, lgnq);
                 for (int e = threadIdx.x; e < nq * Mr; e += 256) {
                     const int q = e >> lgMr, k = e & (Mr - 1);
                     const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
                     const long long sg = (long long)(gblk * G + gq) * run + t0 + j;
                     if (t0 + j < run && sg < (long long)nsteps) {
-                        const float2 v = res[e];
+                        const float2 v = res[q * pitch + k];
                         y[sg * Mr + k] = make_float2(v.x * invM, v.y * invM);
                     }
                 }
@@ -492,7 +495,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const size_t ngroups = (nsteps + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
     const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
-    const size_t lds = (2 * 256 * (size_t)kColHalf + (size_t)M) * sizeof(float2);
+    const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     firpfbch2_col_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist), hist_len,
                                                    reinterpret_cast<const float2 *>(x), h, M,
                                                    reinterpret_cast<const float2 *>(twM), make_pow2_plan(M / nranks),

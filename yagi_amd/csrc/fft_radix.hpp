@@ -45,22 +45,32 @@ __device__ __forceinline__ void dftR(float2 (&v)[R]) {
 template <int R>
 __device__ __forceinline__ constexpr int dftR_pos(int k) { return R == 16 ? dft16_pos(k) : k; }
 
-// One Stockham pass of radix R over `nfr` independent N-point transforms stored [frame][N] in LDS.
+// One Stockham pass of radix R over `nfr` independent N-point transforms stored [frame][pitch] in LDS.
 //   butterfly j in [0, N/R), k = j mod Ns:
 //     dst[(j/Ns)*Ns*R + k + q*Ns] = sum_r src[j + r*N/R] * W_{Ns*R}^{k*r} * W_R^{r*q}
 // twl = LDS (or global) table of W_Ntab^m, N * tw_scale == Ntab.  Ns, N powers of two.
-template <int R, int SIGN>
+// Lane -> (transform, butterfly) mapping:
+//   FRFAST = false: butterfly index fastest (pitch = N).  Fine while one transform's butterflies fill a lane
+//                   group; with many short transforms the lanes of a group sit N float2 apart = on the same
+//                   banks (8-way conflicts for 64-point transforms: SQ_LDS_BANK_CONFLICT was 80 % of the
+//                   channelizers' LDS cycles).
+//   FRFAST = true:  transform index fastest, nfr = 2^lgnfr <= 32, pitch = N + 32/nfr: the 32 lanes of a group
+//                   are nfr transforms x 32/nfr consecutive butterflies, 2*pitch = 2*32/nfr (mod 64) words
+//                   apart -> every read and every last-pass write is conflict-free.
+template <int R, int SIGN, bool FRFAST = false>
 __device__ __forceinline__ void stockham_pass(const float2 *__restrict__ src, float2 *__restrict__ dst,
                                               int N, int Ns, int nfr, const float2 *__restrict__ twl,
-                                              int tw_scale, bool tw_is_forward = true) {
+                                              int tw_scale, bool tw_is_forward = true, int pitch = 0,
+                                              int lgnfr = 0) {
     const int T = N / R;
     const int lgT = 31 - __builtin_clz((unsigned)T);       // N, R powers of two: index math by shifts
     const int total = T * nfr;
     const int tw_k = (N / (Ns * R)) * tw_scale;
+    if (!FRFAST) pitch = N;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int fr = e >> lgT, j = e & (T - 1);
+        const int fr = FRFAST ? (e & (nfr - 1)) : (e >> lgT), j = FRFAST ? (e >> lgnfr) : (e & (T - 1));
         const int k = j & (Ns - 1);
-        const float2 *s = src + fr * N + j;
+        const float2 *s = src + fr * pitch + j;
         float2 v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = s[r * T];
@@ -73,43 +83,51 @@ __device__ __forceinline__ void stockham_pass(const float2 *__restrict__ src, fl
             }
         }
         dftR<R, SIGN>(v);
-        float2 *d = dst + fr * N + (j - k) * R + k;
+        float2 *d = dst + fr * pitch + (j - k) * R + k;
 #pragma unroll
         for (int q = 0; q < R; ++q) d[q * Ns] = v[dftR_pos<R>(q)];
     }
 }
 
-// radix plan for N = 2^lg: as many 16s as possible, then one of 8/4/2
+// radix plan for N = 2^lg: the fewest passes radix <= 16 allows (ceil(lg/4)), with the bits spread evenly over
+// them (64 = 8 x 8 rather than 16 x 4: every pass then has N/8 butterflies per transform, so short transforms
+// keep all lanes of the workgroup busy in every pass)
 struct Pow2Plan { int n; int r[8]; };
 inline Pow2Plan make_pow2_plan(int N) {
     Pow2Plan p{0, {0}};
     int lg = 0;
     while ((1 << lg) < N) ++lg;
-    while (lg >= 4) { p.r[p.n++] = 16; lg -= 4; }
-    if (lg == 3) p.r[p.n++] = 8;
-    else if (lg == 2) p.r[p.n++] = 4;
-    else if (lg == 1) p.r[p.n++] = 2;
+    if (lg == 0) return p;
+    const int np = (lg + 3) / 4;
+    for (int i = 0; i < np; ++i) {
+        const int bits = lg / np + (i < lg % np ? 1 : 0);
+        p.r[p.n++] = 1 << bits;
+    }
     return p;
 }
 
 // all passes of `plan` over nfr transforms; returns the buffer holding the result.
 // Every lane of the workgroup must call it (one __syncthreads per pass).
-template <int SIGN>
+template <int SIGN, bool FRFAST = false>
 __device__ __forceinline__ float2 *lds_fft_pow2(float2 *src, float2 *dst, int N, int nfr,
                                                 const Pow2Plan &plan, const float2 *__restrict__ twl,
-                                                int tw_scale, bool tw_is_forward = true) {
+                                                int tw_scale, bool tw_is_forward = true, int pitch = 0,
+                                                int lgnfr = 0) {
     int Ns = 1;
     for (int f = 0; f < plan.n; ++f) {
         const int R = plan.r[f];
-        if (R == 16) stockham_pass<16, SIGN>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward);
-        else if (R == 8) stockham_pass<8, SIGN>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward);
-        else if (R == 4) stockham_pass<4, SIGN>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward);
-        else stockham_pass<2, SIGN>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward);
+        if (R == 16) stockham_pass<16, SIGN, FRFAST>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward, pitch, lgnfr);
+        else if (R == 8) stockham_pass<8, SIGN, FRFAST>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward, pitch, lgnfr);
+        else if (R == 4) stockham_pass<4, SIGN, FRFAST>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward, pitch, lgnfr);
+        else stockham_pass<2, SIGN, FRFAST>(src, dst, N, Ns, nfr, twl, tw_scale, tw_is_forward, pitch, lgnfr);
         __syncthreads();
         float2 *t = src; src = dst; dst = t;
         Ns *= R;
     }
     return src;
 }
+
+// LDS pitch (float2) of one transform slot when nfr = 2^k <= 32 transforms of <= N points share a pass (FRFAST)
+__host__ __device__ inline int frfast_pitch(int N, int nfr) { return N + 32 / nfr; }
 
 }  // namespace yagi
