@@ -22,6 +22,8 @@
 // LDS once (8 B/sample from HBM), branch dot products from LDS; firpfbch2 (M = 256: the history is
 // ~4 tiles long) reads samples straight from L1/L2 instead (measured faster, profiles/r01_notes.md); the M-point DFTs as Stockham passes in LDS, coalesced
 // [frame][channel] stores (8 or 16 B per input sample).  HBM-bound by construction.
+#include <type_traits>
+
 #include "fft_radix.hpp"
 #include "kernels.hpp"
 
@@ -151,19 +153,22 @@ constexpr int kColHalf = 8;
 #define YG_COL_WGS 1024
 #endif
 
-template <int P>
+// M = 2^LGM is a template parameter so that only the two radix passes M needs are instantiated (with a run-time
+// plan the register allocation is that of the widest radix: 200 VGPRs).
+template <int P, int LGM>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
-                    const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
+                    const float *__restrict__ h, const float2 *__restrict__ twM,
                     float2 *__restrict__ y, size_t nframes, int run) {
+    constexpr int M = 1 << LGM, lgM = LGM;
+    constexpr int R0 = LGM == 6 ? 8 : 16, R1 = M / R0;           // 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
     extern __shared__ __align__(16) unsigned char smem[];
-    const int G = 256 / M;
-    const int nq = G * kColHalf, lgnq = 31 - __builtin_clz((unsigned)nq);      // transforms per half tile
-    const int pitch = frfast_pitch(M, nq);
+    constexpr int G = 256 / M;
+    constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;        // transforms per half tile (kColHalf = 8)
+    constexpr int pitch = M + 32 / nq;                          // = frfast_pitch(M, nq)
     float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 frames][pitch]
     float2 *vb = va + nq * pitch;
     float2 *twl = vb + nq * pitch;                              // M
-    const int lgM = 31 - __builtin_clz((unsigned)M);
     const int g = threadIdx.x >> lgM, c = threadIdx.x & (M - 1);
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     float hc[P];
@@ -171,56 +176,77 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     for (int n = 0; n < P; ++n) hc[n] = h[(M - 1 - c) + n * M];
     const int hist_len = (P - 1) * M;
     const long long x_len = (long long)nframes * M;
-    const size_t ngroups = (nframes + run - 1) / run;
-    for (size_t gblk = blockIdx.x; gblk * G < ngroups; gblk += gridDim.x) {
-        const long long f_begin = (long long)(gblk * G + g) * run;       // may lie past the end: all guarded
-        float2 w[P];                                                     // ring: frame f at slot (f - f_begin) mod P
+    // one workgroup = G consecutive runs of `run` frames (no grid-stride loop); all frame indices below are
+    // 32-bit offsets from the workgroup's first frame
+    const long long wg_first = (long long)blockIdx.x * G * run;
+    const long long wg_left = (long long)nframes - wg_first;                     // > 0
+    const int wg_frames = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
+    const bool full = wg_frames == G * run;          // block-uniform: no per-frame checks anywhere
+    auto group_frames = [&](int gq) {                // frames of group gq that exist
+        const int v = wg_frames - gq * run;
+        return v < 0 ? 0 : (v > run ? run : v);
+    };
+    const long long f_begin = wg_first + (long long)g * run;
+    const int nvalid = group_frames(g);
+    const float2 *xg = x + f_begin * M + c;          // dereferenced for existing frames only
+    float2 w[P];                                     // ring: frame f at slot (f - f_begin) mod P
 #pragma unroll
-        for (int n = 1; n < P; ++n)
-            w[P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + c, x_len);
-        for (int t0 = 0; t0 < run; t0 += kColTile) {
-            float2 xin[kColTile];
+    for (int n = 1; n < P; ++n)
+        w[P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + c, x_len);
+    float2 xa[kColHalf], xb[kColHalf];               // the next two half tiles of this column, in flight
+    auto load8 = [&](float2 (&d)[kColHalf], int t) {
 #pragma unroll
-            for (int j = 0; j < kColTile; ++j) {
-                const long long f = f_begin + t0 + j;
-                xin[j] = (f < (long long)nframes) ? x[f * M + c] : make_float2(0.f, 0.f);
+        for (int j = 0; j < kColHalf; ++j)
+            d[j] = (full || t + j < nvalid) ? xg[(unsigned)(t + j) << lgM] : make_float2(0.f, 0.f);
+    };
+    float2 *yb = y + wg_first * M;
+    // FIR over 8 frames of the column (ring slots static: run, t0 are multiples of 16 and P divides 16), then
+    // the M-point transforms of all G*8 frames of the workgroup and coalesced [frame][channel] stores.  The
+    // column's samples for the half tile after next are requested before the transforms start, so their HBM
+    // latency is hidden behind the LDS passes.
+    auto half_tile = [&](float2 (&xin)[kColHalf], int t, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
+#pragma unroll
+        for (int j = 0; j < kColHalf; ++j) {
+            w[(S0 + j) % P] = xin[j];
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < P; ++n) {
+                const float2 sv = w[(S0 + j - n + 4 * P) % P];
+                acc.x = fmaf(sv.x, hc[n], acc.x);
+                acc.y = fmaf(sv.y, hc[n], acc.y);
             }
-            float2 acc[kColTile];
-#pragma unroll
-            for (int j = 0; j < kColTile; ++j) {
-                w[j % P] = xin[j];
-                acc[j] = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int n = 0; n < P; ++n) {
-                    const float2 sv = w[(j - n + 4 * P) % P];
-                    acc[j].x = fmaf(sv.x, hc[n], acc[j].x);
-                    acc[j].y = fmaf(sv.y, hc[n], acc[j].y);
-                }
-            }
-            // the 16 frames go through the M-point transforms in two halves of 8 so the two LDS buffers
-            // stay at 16 KiB each (4 workgroups per CU)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * pitch + c] = acc[half * kColHalf + j];
-                __syncthreads();
-                float2 *res = lds_fft_pow2<-1, true>(va, vb, M, nq, plan, twl, 1, true, pitch, lgnq);
-                // transform q = g'*8 + j is frame f_begin(g') + t0 + 8*half + j
-                for (int e = threadIdx.x; e < 256 * kColHalf; e += 256) {
-                    const int q = e >> lgM, k = e & (M - 1);
-                    const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
-                    const long long f = (long long)(gblk * G + gq) * run + t0 + j;
-                    if (t0 + j < run && f < (long long)nframes) y[f * M + k] = res[q * pitch + k];
-                }
-                __syncthreads();
-            }
+            va[(g * kColHalf + j) * pitch + c] = acc;
         }
+        if (t + kColTile < run) load8(xin, t + kColTile);
+        __syncthreads();
+        stockham_pass<R0, -1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        stockham_pass<R1, -1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        const float2 *res = va;
+        // transform q = g'*8 + j is frame t + j of group g'
+#pragma unroll
+        for (int i = 0; i < kColHalf; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            const int q = e >> lgM, k = e & (M - 1);
+            const int gq = q / kColHalf, fr = t + (q - gq * kColHalf);
+            if (full || fr < group_frames(gq)) yb[((unsigned)(gq * run + fr) << lgM) + k] = res[q * pitch + k];
+        }
+        __syncthreads();
+    };
+    load8(xa, 0);
+    load8(xb, kColHalf);
+    for (int t0 = 0; t0 < run; t0 += kColTile) {
+        half_tile(xa, t0, std::integral_constant<int, 0>{});
+        half_tile(xb, t0 + kColHalf, std::integral_constant<int, kColHalf>{});
     }
 }
 
-template <int P>
-static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, int M, const cf32 *twM,
+template <int P, int LGM>
+static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
                                cf32 *y, size_t nframes, hipStream_t st) {
+    constexpr int M = 1 << LGM;
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
     // >= ~2048 workgroups
@@ -230,18 +256,19 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     if (run > 256) run = 256;
     const size_t ngroups = (nframes + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
-    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const unsigned grid = (unsigned)nblk;
     const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P>),
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P, LGM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    firpfbch_col_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
-                                                  reinterpret_cast<const float2 *>(x), h, M,
-                                                  reinterpret_cast<const float2 *>(twM), make_pow2_plan(M),
-                                                  reinterpret_cast<float2 *>(y), nframes, (int)run);
+    firpfbch_col_kernel<P, LGM><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
+                                                       reinterpret_cast<const float2 *>(x), h,
+                                                       reinterpret_cast<const float2 *>(twM),
+                                                       reinterpret_cast<float2 *>(y), nframes, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -254,12 +281,18 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
                     const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
     if ((M == 64 || M == 128 || M == 256) && nframes >= 64) {
+#define YG_COL_CASE(PP)                                                                              \
+    case PP:                                                                                         \
+        return M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st)                 \
+             : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st)                \
+                        : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st);
         switch (p) {
-            case 4: return launch_firpfbch_col<4>(hist, x, h, M, twM, y, nframes, st);
-            case 8: return launch_firpfbch_col<8>(hist, x, h, M, twM, y, nframes, st);
-            case 16: return launch_firpfbch_col<16>(hist, x, h, M, twM, y, nframes, st);
+            YG_COL_CASE(4)
+            YG_COL_CASE(8)
+            YG_COL_CASE(16)
             default: break;
         }
+#undef YG_COL_CASE
     }
     // frames per tile: as many as fit the LDS budget (>= 1)
     int F = 4096 / M;
@@ -380,19 +413,23 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
 // 2*P packed FMAs out of registers.  To keep the code free of divergence the even-step taps of the lanes
 // with b >= M/2 (which must see the window BEFORE this pair's sample) are stored rotated by one slot.
 // ---------------------------------------------------------------------------------------------
-template <int P>
+// M = 2^LGM is a template parameter (see firpfbch_col_kernel); SHARDED = a rank's sub-band shard (R > 1: fold to the
+// residue class, then a run-time planned M/R-point transform), otherwise two static radix passes.
+template <int P, int LGM, bool SHARDED>
 __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
-                     const float *__restrict__ h, int M, const float2 *__restrict__ twM, Pow2Plan plan,
-                     int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, even */) {
+                     const float *__restrict__ h, const float2 *__restrict__ twM, Pow2Plan plan,
+                     int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int G = 256 / M, M2 = M / 2, Mr = M / R;
-    const int nq = G * kColHalf, lgnq = 31 - __builtin_clz((unsigned)nq);      // transforms in flight
-    const int pitch = frfast_pitch(M, nq);
+    constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
+    constexpr int R0 = LGM == 6 ? 8 : 16, R1 = M / R0;
+    constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;       // transforms in flight (kColHalf = 8)
+    constexpr int pitch = M + 32 / nq;                          // = frfast_pitch(M, nq)
+    const int Mr = SHARDED ? M / R : M;
+    const int lgMr = 31 - __builtin_clz((unsigned)Mr);
     float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][pitch]
     float2 *vb = va + nq * pitch;
     float2 *twl = vb + nq * pitch;                              // M
-    const int lgM = 31 - __builtin_clz((unsigned)M), lgMr = 31 - __builtin_clz((unsigned)Mr);
     const int g = threadIdx.x >> lgM, b = threadIdx.x & (M - 1);
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     const int bpar = (b >= M2) ? 1 : 0;
@@ -407,86 +444,103 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     }
     const float invM = 1.0f / (float)M;
     const long long x_len = (long long)nsteps * M2;
-    const size_t ngroups = (nsteps + run - 1) / run;
-    for (size_t gblk = blockIdx.x; gblk * G < ngroups; gblk += gridDim.x) {
-        const long long s_begin = (long long)(gblk * G + g) * run;       // even
-        // sample of local pair kk: X[(s_begin + 2kk + bpar)*M2 + pos], kept in ring slot kk mod P
-        float2 w[P];
+    // one workgroup = G consecutive runs of `run` steps; step indices below are 32-bit offsets from its first
+    const long long wg_first = (long long)blockIdx.x * G * run;
+    const long long wg_left = (long long)nsteps - wg_first;
+    const int wg_steps = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
+    const bool full = wg_steps == G * run;
+    auto group_steps = [&](int gq) {
+        const int v = wg_steps - gq * run;
+        return v < 0 ? 0 : (v > run ? run : v);
+    };
+    const long long s_begin = wg_first + (long long)g * run;             // even
+    const int nvalid = group_steps(g);
+    // sample of local pair kk: X[(s_begin + 2kk + bpar)*M2 + pos], kept in ring slot kk mod P
+    const float2 *xg = x + (s_begin + bpar) * M2 + pos;                   // + 2kk*M2 = kk*M
+    float2 w[P];
 #pragma unroll
-        for (int n = 1; n <= P; ++n)                                     // pairs -1 .. -P
-            w[(P - n) % P] = load_hist(hist, hist_len, x, (s_begin - 2 * n + bpar) * M2 + pos, x_len);
-        for (int t0 = 0; t0 < run; t0 += kColTile) {
-            float2 xin[kColHalf];
+    for (int n = 1; n <= P; ++n)                                         // pairs -1 .. -P
+        w[(P - n) % P] = load_hist(hist, hist_len, x, (s_begin - 2 * n + bpar) * M2 + pos, x_len);
+    constexpr int kPairs = kColHalf / 2;                                 // 4 samples feed 8 steps
+    float2 xa[kPairs], xb[kPairs];
+    auto load4 = [&](float2 (&d)[kPairs], int t /* first step of the half tile */) {
 #pragma unroll
-            for (int kk = 0; kk < kColHalf; ++kk) {
-                const long long sx = s_begin + t0 + 2 * kk + bpar;
-                xin[kk] = (sx < (long long)nsteps) ? x[sx * M2 + pos] : make_float2(0.f, 0.f);
+        for (int kk = 0; kk < kPairs; ++kk)
+            d[kk] = (full || t + 2 * kk + bpar < nvalid) ? xg[(unsigned)(t / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+    };
+    float2 *yb = y + wg_first * Mr;
+    auto half_tile = [&](float2 (&xin)[kPairs], int t, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;                       // ring slot of the half tile's first pair
+#pragma unroll
+        for (int kk = 0; kk < kPairs; ++kk) {
+            const float2 old = w[(S0 + kk) % P];
+            // even step: the early-fed half already sees the new sample, the late-fed half the old one
+            w[(S0 + kk) % P] = bpar ? old : xin[kk];
+            float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const float2 sv = w[(S0 + kk - m + 4 * P) % P];
+                a0.x = fmaf(sv.x, h0r[m], a0.x);
+                a0.y = fmaf(sv.y, h0r[m], a0.y);
             }
-            float2 acc[kColTile];
+            w[(S0 + kk) % P] = xin[kk];                                   // odd step: everybody is fed
 #pragma unroll
-            for (int kk = 0; kk < kColHalf; ++kk) {
-                const float2 old = w[kk % P];
-                // even step: the early-fed half already sees the new sample, the late-fed half the old one
-                w[kk % P] = bpar ? old : xin[kk];
-                float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int m = 0; m < P; ++m) {
-                    const float2 sv = w[(kk - m + 4 * P) % P];
-                    a0.x = fmaf(sv.x, h0r[m], a0.x);
-                    a0.y = fmaf(sv.y, h0r[m], a0.y);
-                }
-                w[kk % P] = xin[kk];                                      // odd step: everybody is fed
-#pragma unroll
-                for (int m = 0; m < P; ++m) {
-                    const float2 sv = w[(kk - m + 4 * P) % P];
-                    a1.x = fmaf(sv.x, h1[m], a1.x);
-                    a1.y = fmaf(sv.y, h1[m], a1.y);
-                }
-                acc[2 * kk] = a0;
-                acc[2 * kk + 1] = a1;
+            for (int m = 0; m < P; ++m) {
+                const float2 sv = w[(S0 + kk - m + 4 * P) % P];
+                a1.x = fmaf(sv.x, h1[m], a1.x);
+                a1.y = fmaf(sv.y, h1[m], a1.y);
             }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int j = 0; j < kColHalf; ++j) va[(g * kColHalf + j) * pitch + b] = acc[half * kColHalf + j];
-                __syncthreads();
-                float2 *srcb = va, *dstb = vb;
-                if (R > 1) {
-                    for (int e = threadIdx.x; e < nq * Mr; e += 256) {
-                        const int q = e >> lgMr, bq = e & (Mr - 1);
-                        float2 a = make_float2(0.f, 0.f);
-                        for (int aa = 0; aa < R; ++aa) {
-                            float2 wv = twl[((aa * rank) % R) * Mr];
-                            wv.y = -wv.y;
-                            a = cadd(a, cmul(va[q * pitch + Mr * aa + bq], wv));
-                        }
-                        float2 w2 = twl[(bq * rank) & (M - 1)];
-                        w2.y = -w2.y;
-                        vb[q * pitch + bq] = cmul(a, w2);
-                    }
-                    __syncthreads();
-                    srcb = vb;
-                    dstb = va;
+            va[(g * kColHalf + 2 * kk) * pitch + b] = a0;
+            va[(g * kColHalf + 2 * kk + 1) * pitch + b] = a1;
+        }
+        if (t + kColTile < run) load4(xin, t + kColTile);                 // in flight during the transforms
+        __syncthreads();
+        const float2 *res;
+        if constexpr (SHARDED) {
+            // fold to the rank's residue class: Z[b'] = W_M^{-b' r} sum_a W_R^{-a r} V[Mr*a + b']
+            for (int e = threadIdx.x; e < nq * Mr; e += 256) {
+                const int q = e >> lgMr, bq = e & (Mr - 1);
+                float2 a = make_float2(0.f, 0.f);
+                for (int aa = 0; aa < R; ++aa) {
+                    float2 wv = twl[((aa * rank) % R) * Mr];
+                    wv.y = -wv.y;
+                    a = cadd(a, cmul(va[q * pitch + Mr * aa + bq], wv));
                 }
-                float2 *res = lds_fft_pow2<+1, true>(srcb, dstb, Mr, nq, plan, twl, R, true, pitch, lgnq);
-                for (int e = threadIdx.x; e < nq * Mr; e += 256) {
-                    const int q = e >> lgMr, k = e & (Mr - 1);
-                    const int gq = q / kColHalf, j = q - gq * kColHalf + half * kColHalf;
-                    const long long sg = (long long)(gblk * G + gq) * run + t0 + j;
-                    if (t0 + j < run && sg < (long long)nsteps) {
-                        const float2 v = res[q * pitch + k];
-                        y[sg * Mr + k] = make_float2(v.x * invM, v.y * invM);
-                    }
-                }
-                __syncthreads();
+                float2 w2 = twl[(bq * rank) & (M - 1)];
+                w2.y = -w2.y;
+                vb[q * pitch + bq] = cmul(a, w2);
+            }
+            __syncthreads();
+            res = lds_fft_pow2<+1, true>(vb, va, Mr, nq, plan, twl, R, true, pitch, lgnq);
+        } else {
+            stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+            __syncthreads();
+            stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+            __syncthreads();
+            res = va;
+        }
+        for (int e = threadIdx.x; e < nq * Mr; e += 256) {
+            const int q = e >> lgMr, k = e & (Mr - 1);
+            const int gq = q / kColHalf, sr = t + (q - gq * kColHalf);
+            if (full || sr < group_steps(gq)) {
+                const float2 v = res[q * pitch + k];
+                yb[(size_t)(gq * run + sr) * Mr + k] = make_float2(v.x * invM, v.y * invM);
             }
         }
+        __syncthreads();
+    };
+    load4(xa, 0);
+    load4(xb, kColHalf);
+    for (int t0 = 0; t0 < run; t0 += kColTile) {
+        half_tile(xa, t0, std::integral_constant<int, 0>{});
+        half_tile(xb, t0 + kColHalf, std::integral_constant<int, kPairs>{});
     }
 }
 
-template <int P>
-static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M,
+template <int P, int LGM>
+static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, const float *h,
                                 const cf32 *twM, int rank, int nranks, cf32 *y, size_t nsteps, hipStream_t st) {
+    constexpr int M = 1 << LGM;
     const int G = 256 / M;
     size_t run = nsteps / ((size_t)YG_COL_WGS * G);
     run = run / kColTile * kColTile;
@@ -494,12 +548,18 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     if (run > 512) run = 512;
     const size_t ngroups = (nsteps + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
-    const unsigned grid = (unsigned)(nblk < 65536 ? nblk : 65536);
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const unsigned grid = (unsigned)nblk;
     const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
-    firpfbch2_col_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist), hist_len,
-                                                   reinterpret_cast<const float2 *>(x), h, M,
-                                                   reinterpret_cast<const float2 *>(twM), make_pow2_plan(M / nranks),
-                                                   rank, nranks, reinterpret_cast<float2 *>(y), nsteps, (int)run);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (nranks > 1)
+        firpfbch2_col_kernel<P, LGM, true><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, make_pow2_plan(M / nranks),
+                                                                  rank, nranks, fy, nsteps, (int)run);
+    else
+        firpfbch2_col_kernel<P, LGM, false><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, Pow2Plan{0, {0}}, 0, 1,
+                                                                   fy, nsteps, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -514,12 +574,18 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     const size_t lead = (size_t)(p - 1) * M + M2;
     if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
     if ((M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 && is_pow2(M / nranks)) {
+#define YG_COL2_CASE(PP)                                                                                          \
+    case PP:                                                                                                      \
+        return M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
+             : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)     \
+                        : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st);
         switch (p) {
-            case 2: return launch_firpfbch2_col<2>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
-            case 4: return launch_firpfbch2_col<4>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
-            case 8: return launch_firpfbch2_col<8>(hist, hist_len, x, h, M, twM, rank, nranks, y, nsteps, st);
+            YG_COL2_CASE(2)
+            YG_COL2_CASE(4)
+            YG_COL2_CASE(8)
             default: break;
         }
+#undef YG_COL2_CASE
     }
     int S = 4096 / M;
     if (S < 1) S = 1;
