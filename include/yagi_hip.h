@@ -265,6 +265,48 @@ YAGI_FIRINTERP_API(rrrf, float, float)
 YAGI_FIRINTERP_API(crcf, yagi_cf32, float)
 YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
 
+/* ---- Rresamp<T,Coeff>: src/filter/resampler/rresamp.rs:8-183 (rational-rate resampler P/Q) -----
+ *   create          new(interp, decim, m, h)            :28-57   bank = FirPfbFilter::new(interp, h, 2*interp*m)
+ *   create_kaiser   new_kaiser(interp, decim, m, bw, as) :59-82   rates reduced by their gcd (block_len = gcd),
+ *                                                                bw < 0 picks the default, scale 2 bw sqrt(Q/P)
+ *   create_default  new_default(interp, decim)           :99-104  m 12, bw 0.5, 60 dB
+ *   reset / set_scale / get_scale                        :106-116
+ *   get_params      get_interp / get_decim / get_delay (= m) / get_block_len  :118-148
+ *                   (get_rate = P/Q, get_p = P*block_len, get_q = Q*block_len follow from them)
+ *   write           write(buf)                           :150-152 pushes samples without producing output
+ *   execute         execute(x, y)                        :154-161 Q*block_len inputs -> P*block_len outputs
+ *   execute_block   execute_block(x, n, y)               :163-170 n times execute.  (For block_len > 1 the
+ *                   reference slices x and y by Q and P here and panics inside execute; this engine advances
+ *                   by Q*block_len and P*block_len like liquid-dsp's rresamp_execute_block.)
+ *   new_prototype (:84-97) needs fir_design_prototype (design code out of scope): create() with external taps.
+ * Device form: rresamp_kernel -- the branch schedule is static (output n of a block = branch (nQ) mod P after
+ * input floor(nQ/P)), so every output is an independent 2m-tap dot product. */
+#define YAGI_RRESAMP_API(K, T, C)                                                                   \
+    typedef struct yagi_hip_rresamp_##K##_s *yagi_hip_rresamp_##K;                                  \
+    int yagi_hip_rresamp_##K##_create(size_t interp, size_t decim, size_t m, const C *h,            \
+                                      size_t h_len, yagi_hip_rresamp_##K *q);                       \
+    int yagi_hip_rresamp_##K##_create_kaiser(size_t interp, size_t decim, size_t m, float bw,       \
+                                             float as_, yagi_hip_rresamp_##K *q);                   \
+    int yagi_hip_rresamp_##K##_create_default(size_t interp, size_t decim, yagi_hip_rresamp_##K *q);\
+    int yagi_hip_rresamp_##K##_destroy(yagi_hip_rresamp_##K q);                                     \
+    int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s);                 \
+    int yagi_hip_rresamp_##K##_reset(yagi_hip_rresamp_##K q);                                       \
+    int yagi_hip_rresamp_##K##_set_scale(yagi_hip_rresamp_##K q, C scale);                          \
+    int yagi_hip_rresamp_##K##_get_scale(yagi_hip_rresamp_##K q, C *scale);                         \
+    int yagi_hip_rresamp_##K##_get_params(yagi_hip_rresamp_##K q, size_t *interp, size_t *decim,    \
+                                          size_t *m, size_t *block_len);                            \
+    int yagi_hip_rresamp_##K##_write(yagi_hip_rresamp_##K q, const T *x, size_t n);                 \
+    int yagi_hip_rresamp_##K##_execute(yagi_hip_rresamp_##K q, const T *x, size_t nx, T *y,         \
+                                       size_t ny);                                                  \
+    int yagi_hip_rresamp_##K##_execute_block(yagi_hip_rresamp_##K q, const T *x, size_t nx,         \
+                                             size_t n, T *y, size_t ny);                            \
+    int yagi_hip_rresamp_##K##_execute_block_dev(yagi_hip_rresamp_##K q, const T *x_dev, size_t n,  \
+                                                 T *y_dev);
+
+YAGI_RRESAMP_API(rrrf, float, float)
+YAGI_RRESAMP_API(crcf, yagi_cf32, float)
+YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
+
 /* Which kernel execute_block uses.  0 = auto (always a direct form), 1 = general direct-form kernel
  * (fir_kernels.hip), 4 = overlap-save fast convolution (<= 2049 taps; stream_kernels.hip).
  * crcf also: 2 = register-sliding direct form (<= 1024 taps), 3 = MFMA Toeplitz direct form (<= 256 taps).

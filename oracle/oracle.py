@@ -392,6 +392,70 @@ class FirInterpolationFilter:
         return self.execute(0.0)
 
 
+class Rresamp:
+    """Restatement of Rresamp<T,Coeff> (rresamp.rs:28-183): a FirPfbFilter of `interp` branches and 2m taps each;
+    per primitive block push Q samples and, after each push, emit while index < P { branch index; index += Q },
+    then index -= P (execute_primitive, :162-183).  execute_block advances by Q*block_len / P*block_len per
+    execute (liquid-dsp's behaviour; the reference slices by Q / P there and panics for block_len > 1)."""
+
+    def __init__(self, kind, interp, decim, m, h):
+        if interp == 0 or decim == 0 or m == 0:
+            raise ValueError("config")
+        cdt = KINDS[kind][1]
+        h = _as(h, cdt)
+        self.kind, self.p, self.q, self.m, self.block_len = kind, interp, decim, m, 1
+        self.pfb = FirPfbFilter(kind, interp, h, 2 * interp * m)
+
+    @classmethod
+    def new_kaiser(cls, kind, interp, decim, m, bw, as_):                    # :59-82
+        g = int(np.gcd(interp, decim))
+        interp, decim = interp // g, decim // g
+        if bw < 0:
+            bw = 0.5 if interp > decim else np.float32(0.5) * np.float32(interp) / np.float32(decim)
+        elif bw > 0.5:
+            raise ValueError("config")
+        bw = np.float32(bw)
+        hf = fir_design_kaiser(2 * interp * m + 1, float(bw / np.float32(interp)), as_, 0.0)
+        q = cls(kind, interp, decim, m, hf.astype(KINDS[kind][1]))
+        q.set_scale(np.float32(2.0) * bw * np.sqrt(np.float32(decim) / np.float32(interp)))
+        q.block_len = g
+        return q
+
+    @classmethod
+    def new_default(cls, kind, interp, decim):                               # :99-104
+        return cls.new_kaiser(kind, interp, decim, 12, 0.5, 60.0)
+
+    def set_scale(self, s):
+        self.pfb.set_scale(s)
+
+    def reset(self):
+        self.pfb.reset()
+
+    def write(self, buf):
+        self.pfb.write(buf)
+
+    def _primitive(self, x):
+        y, index = [], 0
+        for i in range(self.q):
+            self.pfb.push(x[i])
+            while index < self.p:
+                y.append(self.pfb.execute(index))
+                index += self.q
+            index -= self.p
+        assert index == 0 and len(y) == self.p
+        return y
+
+    def execute(self, x):
+        y = []
+        for i in range(self.block_len):
+            y += self._primitive(x[i * self.q:(i + 1) * self.q])
+        return np.array(y, dtype=self.pfb.tdt)
+
+    def execute_block(self, x, n):
+        step = self.q * self.block_len
+        return np.concatenate([self.execute(x[i * step:(i + 1) * step]) for i in range(n)])
+
+
 def fir_block_f64(kind, h, x, M=1, n=None, scale=1.0):
     """f64 truth: y[i] = scale * sum_k h[k] x[i*M-k], zero history."""
     tdt, cdt, code = KINDS[kind]

@@ -283,3 +283,24 @@ def test_spgram_oracle_noise_floor(oracle, nfft, wtype, wlen, delay):
     assert np.all(np.abs(psd + 80.0) <= 1.0)
     q.clear()
     assert q.num_samples == 0 and q.num_samples_total == n and q.num_transforms == 0
+
+
+# ---- rresamp: the reference's own acceptance test for the schedule (rresamp.rs:198-238) ---------
+@pytest.mark.parametrize("P", [1, 2, 3, 6, 8, 9])
+def test_rresamp_oracle_partition(oracle, P, Q=5, m=15, n=20):
+    """autotest_rresamp_crcf_part_P*_Q5 on the restatement: one 2n-block run == n blocks + a second resampler
+    primed with the last m*Q inputs by write(); plus the P outputs / Q inputs bookkeeping of execute_primitive"""
+    q0 = oracle.Rresamp.new_kaiser("crcf", P, Q, m, 0.5, 60.0)
+    q1 = oracle.Rresamp.new_kaiser("crcf", P, Q, m, 0.5, 60.0)
+    N = 2 * Q * n
+    i = np.arange(N)
+    ham = (0.53836 - 0.46164 * np.cos(2 * np.pi * i / (N - 1))).astype(np.float32)
+    x = (ham * np.exp(2j * np.pi * 0.037 * i)).astype(np.complex64)
+    y0 = q0.execute_block(x, 2 * n)
+    assert y0.shape == (2 * P * n,)
+    q0.reset()
+    ya = q0.execute_block(x[:Q * n], n)
+    for k in range(m):
+        q1.write(x[Q * n - (m - k) * Q: Q * n - (m - k - 1) * Q])
+    yb = q1.execute_block(x[Q * n:], n)
+    np.testing.assert_allclose(np.concatenate([ya, yb]), y0, atol=1e-12, rtol=0)

@@ -28,7 +28,7 @@ from ._capi import cf32, lib
 __all__ = [
     "YagiError", "InternalError", "ConfigError", "ValueError_", "RangeError", "ModeError",
     "NoConvergenceError", "DeviceError", "Direction", "dotprod", "FirFilter", "FirDecimationFilter",
-    "FirPfbFilter", "FirInterpolationFilter", "FftFilt", "Fft", "fft_run", "Spgram", "WindowType", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
+    "FirPfbFilter", "FirInterpolationFilter", "Rresamp", "FftFilt", "Fft", "fft_run", "Spgram", "WindowType", "FirFftStream", "FirPfbCh", "FirPfbCh2", "DeviceArray",
     "fir_design_kaiser", "device_count", "synchronize", "gen_complex_dev", "gen_real_dev",
 ]
 
@@ -498,6 +498,73 @@ class FirInterpolationFilter(_FirBase):
         y = np.empty(self.get_interp_rate(), self.T)
         _check(self._fn("flush")(self._h, _ptr(y), y.size))
         return y
+
+
+class Rresamp(_FirBase):
+    """Rresamp<T,Coeff> (src/filter/resampler/rresamp.rs): rational-rate resampler, P outputs per Q inputs."""
+
+    def __init__(self, kind, interp, decim, m, h):           # new(interp, decim, m, h) :28-57
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_rresamp_{kind}_"
+        h = _arr(h, self.Cdt)
+        hd = C.c_void_p()
+        _check(self._fn("create")(interp, decim, m, _ptr(h), h.size, C.byref(hd)))
+        self._h = hd
+
+    @classmethod
+    def _from(cls, kind, creator, *args):
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_rresamp_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn(creator)(*args, C.byref(hd)))
+        self._h = hd
+        return self
+
+    @classmethod
+    def new_kaiser(cls, kind, interp, decim, m, bw, as_):    # :59-82
+        return cls._from(kind, "create_kaiser", interp, decim, m, bw, as_)
+
+    @classmethod
+    def new_default(cls, kind, interp, decim):               # :99-104
+        return cls._from(kind, "create_default", interp, decim)
+
+    def _params(self):
+        v = [C.c_size_t() for _ in range(4)]
+        _check(self._fn("get_params")(self._h, *[C.byref(a) for a in v]))
+        return tuple(a.value for a in v)                     # interp, decim, m, block_len
+
+    def get_interp(self): return self._params()[0]           # :138-140
+    def get_decim(self): return self._params()[1]            # :146-148
+    def get_delay(self): return self._params()[2]            # :118-120
+    def get_block_len(self): return self._params()[3]        # :122-124
+    def get_rate(self):                                      # :126-128
+        p, q, _, _ = self._params()
+        return np.float32(p) / np.float32(q)
+    def get_p(self): return self._params()[0] * self._params()[3]     # :130-132
+    def get_q(self): return self._params()[1] * self._params()[3]     # :142-144
+
+    def write(self, buf):                                    # :150-152
+        buf = _arr(buf, self.T)
+        _check(self._fn("write")(self._h, _ptr(buf), buf.size))
+
+    def execute(self, x):                                    # :154-161  Q*block_len in -> P*block_len out
+        x = _arr(x, self.T)
+        y = np.empty(self.get_p(), self.T)
+        _check(self._fn("execute")(self._h, _ptr(x), x.size, _ptr(y), y.size))
+        return y
+
+    def execute_block(self, x, n):                           # :163-170  n times execute
+        x = _arr(x, self.T)
+        y = np.empty(n * self.get_p(), self.T)
+        _check(self._fn("execute_block")(self._h, _ptr(x), x.size, n, _ptr(y), y.size))
+        return y
+
+    def execute_block_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def clone(self):
+        raise NotImplementedError("Rresamp.clone is not part of the C ABI yet")
 
 
 class FftFilt(_FirBase):

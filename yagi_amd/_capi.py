@@ -138,6 +138,20 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute_block", vp, vp, sz, vp, sz)
     _sig(p + "execute_block_dev", vp, vp, sz, vp)
     _sig(p + "flush", vp, vp, sz)
+    p = f"yagi_hip_rresamp_{_k}_"
+    _sig(p + "create", sz, sz, sz, vp, sz, pvp)
+    _sig(p + "create_kaiser", sz, sz, sz, f32, f32, pvp)
+    _sig(p + "create_default", sz, sz, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "reset", vp)
+    _sig(p + "set_scale", vp, _Cc)
+    _sig(p + "get_scale", vp, vp)
+    _sig(p + "get_params", vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
+    _sig(p + "write", vp, vp, sz)
+    _sig(p + "execute", vp, vp, sz, vp, sz)
+    _sig(p + "execute_block", vp, vp, sz, sz, vp, sz)
+    _sig(p + "execute_block_dev", vp, vp, sz, vp)
     p = f"yagi_hip_fftfilt_{_k}_"
     _sig(p + "create", vp, sz, sz, pvp)
     _sig(p + "destroy", vp)

@@ -1155,6 +1155,164 @@ YAGI_FIRINTERP_IMPL(rrrf, RRRF, float, float)
 YAGI_FIRINTERP_IMPL(crcf, CRCF, yagi_cf32, float)
 YAGI_FIRINTERP_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
 
+// ---- Rresamp (src/filter/resampler/rresamp.rs) ----------------------------------------------------------
+namespace yagi {
+
+static size_t gcd_sz(size_t a, size_t b) {
+    while (b) { const size_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+template <class K>
+struct RresampObj {
+    using T = typename K::T;
+    using C = typename K::C;
+    FirPfb<K> bank;                      // P branches of 2m taps (rresamp.rs:40)
+    int P = 0, Q = 0, m = 0, block_len = 1;
+
+    int init(size_t interp, size_t decim, size_t m_, const C *h, size_t h_len) {      // :28-57
+        if (interp == 0) return fail(YAGI_ERR_CONFIG, "interpolation rate must be greater than zero");
+        if (decim == 0) return fail(YAGI_ERR_CONFIG, "decimation rate must be greater than zero");
+        if (m_ == 0) return fail(YAGI_ERR_CONFIG, "filter semi-length must be greater than zero");
+        if (interp > (size_t)1 << 15 || decim > (size_t)1 << 15 || m_ > (size_t)1 << 15)
+            return fail(YAGI_ERR_CONFIG, "rresamp: rate or filter too large");
+        if (h_len < 2 * interp * m_) return fail(YAGI_ERR_CONFIG, "rresamp: need 2*interp*m filter coefficients");
+        YG_TRY(bank.init(interp, h, 2 * interp * m_));
+        P = (int)interp; Q = (int)decim; m = (int)m_;
+        block_len = 1;
+        return YAGI_OK;
+    }
+    // nblocks primitive blocks: nblocks*Q inputs -> nblocks*P outputs (device pointers); :162-183
+    int blocks_dev(const T *x, size_t nblocks, T *y) {
+        YG_TRY(bank.w.flush(bank.st));
+        YG_TRY((launch_rresamp<K>(bank.w.dev(), x, bank.taps.template as<C>(), P, Q, bank.Ls, bank.scale, y,
+                                  nblocks, bank.st)));
+        return bank.w.advance(x, nblocks * (size_t)Q, bank.st);
+    }
+    int blocks_host(const T *x, size_t nblocks, T *y) {
+        if (nblocks == 0) return YAGI_OK;
+        YG_TRY(bank.ws.x.ensure(nblocks * (size_t)Q * sizeof(T)));
+        YG_TRY(bank.ws.y.ensure(nblocks * (size_t)P * sizeof(T)));
+        YG_TRY(upload(bank.ws.x.p, x, nblocks * (size_t)Q * sizeof(T), bank.st));
+        YG_TRY(blocks_dev(bank.ws.x.template as<T>(), nblocks, bank.ws.y.template as<T>()));
+        return download(y, bank.ws.y.p, nblocks * (size_t)P * sizeof(T), bank.st);
+    }
+};
+
+}  // namespace yagi
+
+#define YAGI_RRESAMP_IMPL(K, KT, T, C)                                                              \
+    struct yagi_hip_rresamp_##K##_s : RresampObj<KT> {};                                            \
+    extern "C" {                                                                                    \
+    int yagi_hip_rresamp_##K##_create(size_t interp, size_t decim, size_t m, const C *h,            \
+                                      size_t h_len, yagi_hip_rresamp_##K *q) {                      \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
+        auto o = std::make_unique<yagi_hip_rresamp_##K##_s>();                                      \
+        YG_TRY(o->init(interp, decim, m, h, h_len));                                                \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_create_kaiser(size_t interp, size_t decim, size_t m, float bw,       \
+                                             float as_, yagi_hip_rresamp_##K *q) {                  \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (interp == 0 || decim == 0) return fail(YAGI_ERR_CONFIG, "gcd: arguments must be greater than zero"); \
+        const size_t g = gcd_sz(interp, decim);                          /* rresamp.rs:60-62 */     \
+        interp /= g;                                                                                \
+        decim /= g;                                                                                 \
+        if (bw < 0.0f) bw = interp > decim ? 0.5f : 0.5f * (float)interp / (float)decim;            \
+        else if (bw > 0.5f) return fail(YAGI_ERR_CONFIG, "invalid bandwidth (%g), must be less than 0.5", (double)bw); \
+        if (m == 0) return fail(YAGI_ERR_CONFIG, "filter semi-length must be greater than zero");   \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(2 * interp * m + 1, bw / (float)interp, as_, 0.0f, hf));               \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
+        YG_TRY(yagi_hip_rresamp_##K##_create(interp, decim, m, hc.data(), hc.size(), q));           \
+        (*q)->bank.scale = to_c(2.0f * bw * std::sqrt((float)decim / (float)interp), (C *)nullptr); \
+        (*q)->block_len = (int)g;                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_create_default(size_t interp, size_t decim, yagi_hip_rresamp_##K *q) { \
+        return yagi_hip_rresamp_##K##_create_kaiser(interp, decim, 12, 0.5f, 60.0f, q);  /* :99-104 */ \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_destroy(yagi_hip_rresamp_##K q) {                                    \
+        delete q;                                                                                   \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s) {                \
+        CHECK_Q(q);                                                                                 \
+        YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
+        q->bank.st = to_stream(s);                                                                  \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_reset(yagi_hip_rresamp_##K q) {                                      \
+        CHECK_Q(q);                                                                                 \
+        return q->bank.w.reset(q->bank.st);                                                         \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_set_scale(yagi_hip_rresamp_##K q, C scale) {                         \
+        CHECK_Q(q);                                                                                 \
+        q->bank.scale = scale;                                                                      \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_get_scale(yagi_hip_rresamp_##K q, C *scale) {                        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(scale);                                                                           \
+        *scale = q->bank.scale;                                                                     \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_get_params(yagi_hip_rresamp_##K q, size_t *interp, size_t *decim,    \
+                                          size_t *m, size_t *block_len) {                           \
+        CHECK_Q(q);                                                                                 \
+        if (interp) *interp = (size_t)q->P;                                                         \
+        if (decim) *decim = (size_t)q->Q;                                                           \
+        if (m) *m = (size_t)q->m;                                                                   \
+        if (block_len) *block_len = (size_t)q->block_len;                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_write(yagi_hip_rresamp_##K q, const T *x, size_t n) {                \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        for (size_t i = 0; i < n; ++i) q->bank.w.push(x[i]);                                        \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_execute(yagi_hip_rresamp_##K q, const T *x, size_t nx, T *y,         \
+                                       size_t ny) {                                                 \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        const size_t bl = (size_t)q->block_len;                                                     \
+        if (nx < bl * (size_t)q->Q) return fail(YAGI_ERR_RANGE, "input must hold Q*block_len samples"); \
+        if (ny < bl * (size_t)q->P) return fail(YAGI_ERR_RANGE, "output must hold P*block_len samples"); \
+        return q->blocks_host(x, bl, y);                                                            \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_execute_block(yagi_hip_rresamp_##K q, const T *x, size_t nx,         \
+                                             size_t n, T *y, size_t ny) {                           \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        const size_t nb = n * (size_t)q->block_len;                                                 \
+        if (nx < nb * (size_t)q->Q) return fail(YAGI_ERR_RANGE, "input must hold n*Q*block_len samples"); \
+        if (ny < nb * (size_t)q->P) return fail(YAGI_ERR_RANGE, "output must hold n*P*block_len samples"); \
+        return q->blocks_host(x, nb, y);                                                            \
+    }                                                                                               \
+    int yagi_hip_rresamp_##K##_execute_block_dev(yagi_hip_rresamp_##K q, const T *x, size_t n,      \
+                                                 T *y) {                                            \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->blocks_dev(x, n * (size_t)q->block_len, y);                                       \
+    }                                                                                               \
+    }
+
+YAGI_RRESAMP_IMPL(rrrf, RRRF, float, float)
+YAGI_RRESAMP_IMPL(crcf, CRCF, yagi_cf32, float)
+YAGI_RRESAMP_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)
+
 // ---- Spgram (src/fft/spgram.rs) -----------------------------------------------------------------------
 namespace yagi {
 

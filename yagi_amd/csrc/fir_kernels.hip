@@ -227,4 +227,60 @@ template int launch_firpfb_select<RRRF>(const float *, const float *, const floa
 template int launch_firpfb_select<CRCF>(const cf32 *, const cf32 *, const float *, const uint32_t *, int, int, float, cf32 *, size_t, hipStream_t);
 template int launch_firpfb_select<CCCF>(const cf32 *, const cf32 *, const cf32 *, const uint32_t *, int, int, cf32, cf32 *, size_t, hipStream_t);
 
+// ---------------------------------------------------------------------------------------------
+// Rresamp<T,Coeff>::execute_primitive over many blocks (rresamp.rs:162-183): every Q inputs give P
+// outputs; output n of a block is branch (n Q) mod P of the bank, evaluated after input floor(n Q / P)
+// of that block has been pushed -- a static schedule, so every output is an independent Ls-tap dot
+// product:   y[blk P + n] = scale * sum_k hb[(nQ) mod P][k] X[blk Q + floor(nQ/P) - k].
+// One lane per output; the tile's input span sits in LDS, the bank is gathered through L1/L2.
+// ---------------------------------------------------------------------------------------------
+template <class K>
+__global__ void __launch_bounds__(256)
+rresamp_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+               const typename K::C *__restrict__ hb, int P, int Q, int Ls, typename K::C scale,
+               typename K::T *__restrict__ y, size_t nblocks, int tile_blocks) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    const size_t b0 = (size_t)blockIdx.x * tile_blocks;
+    const int nb = (int)((nblocks - b0) < (size_t)tile_blocks ? (nblocks - b0) : (size_t)tile_blocks);
+    const long long base = (long long)b0 * Q - (Ls - 1);
+    const int span = nb * Q + Ls - 1;
+    for (int i = threadIdx.x; i < span; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    __syncthreads();
+    const int nout = nb * P;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int bl = o / P, n = o - bl * P;
+        const int nq = n * Q, i = nq / P, br = nq - i * P;
+        const C *hrow = hb + (size_t)br * Ls;
+        const T *xp = xs + (Ls - 1) + bl * Q + i;
+        T acc = zero_of<T>();
+        for (int k = 0; k < Ls; ++k) acc = mac(acc, xp[-k], hrow[k]);
+        y[b0 * P + o] = mul(acc, scale);
+    }
+}
+
+template <class K>
+int launch_rresamp(const typename K::T *win, const typename K::T *x, const typename K::C *hb, int P, int Q,
+                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st) {
+    using T = typename K::T;
+    if (nblocks == 0) return YAGI_OK;
+    // blocks per tile: ~1024 outputs or inputs, whichever is larger, inside the LDS budget
+    const int big = P > Q ? P : Q;
+    int tb = 1024 / big;
+    if (tb < 1) tb = 1;
+    auto bytes = [&](int t) { return ((size_t)t * Q + Ls - 1) * sizeof(T); };
+    while (tb > 1 && bytes(tb) > kFirLdsBudget) tb /= 2;
+    if (bytes(tb) > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "rresamp: Q and the branch length do not fit the LDS (%d, %d)", Q, Ls);
+    const size_t nblk = (nblocks + tb - 1) / tb;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    rresamp_kernel<K><<<(unsigned)nblk, 256, bytes(tb), st>>>(win, x, hb, P, Q, Ls, scale, y, nblocks, tb);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+template int launch_rresamp<RRRF>(const float *, const float *, const float *, int, int, int, float, float *, size_t, hipStream_t);
+template int launch_rresamp<CRCF>(const cf32 *, const cf32 *, const float *, int, int, int, float, cf32 *, size_t, hipStream_t);
+template int launch_rresamp<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, int, cf32, cf32 *, size_t, hipStream_t);
+
 }  // namespace yagi

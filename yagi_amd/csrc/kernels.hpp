@@ -44,6 +44,11 @@ int launch_firpfb_select(const typename K::T *win, const typename K::T *x, const
                          const uint32_t *idx, int nf, int Ls, typename K::C scale,
                          typename K::T *y, size_t n, hipStream_t st);
 
+// Rresamp: y[blk*P + n] = scale * sum_k hb[(n*Q) % P][k] X[blk*Q + (n*Q)/P - k], n < P, blk < nblocks
+template <class K>
+int launch_rresamp(const typename K::T *win, const typename K::T *x, const typename K::C *hb, int P, int Q,
+                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st);
+
 // ---- stream_kernels.hip (crcf M=1 hot case; headline fused FIR -> 4096-pt FFT) -----------------
 // taps_pad = h zero-padded to Lp = roundup(L, 32) floats.
 constexpr int kSlideMaxTaps = 1024;
