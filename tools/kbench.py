@@ -58,7 +58,7 @@ if "chan2" in what:
     c2 = ya.FirPfbCh2.new_kaiser(256, 4, 60.0)
     c2.set_stream(st.cuda_stream)
     cases["firpfbch2 M=256 m=4"] = (lambda: c2.analyzer_execute_dev(x, n // 128, y), 24 * n)
-if "decim" in what:
+if "decim" in what or "decim2" in what:
     d = ya.FirDecimationFilter.new_kaiser("crcf", 4, 8, 60.0)
     d.set_stream(st.cuda_stream)
     cases["firdecim_crcf M=4 L=65"] = (lambda: d.execute_block_dev(x, n // 4, y), 10 * n)

@@ -14,6 +14,8 @@
 // ds_read) and one broadcast tap.  Algorithmic HBM traffic: sizeof(T)*(M + 1) bytes per output
 // (+ the (L-1)-sample halo per tile, which is L2-resident).  This is the general kernel (any
 // L, M, type); the crcf M=1 hot case has an MFMA version in fir_mfma.hip.
+#include <type_traits>
+
 #include "devmath.hpp"
 #include "kernels.hpp"
 
@@ -29,11 +31,16 @@ __device__ __forceinline__ T load_stream(const T *__restrict__ win, const T *__r
     return (idx < 0) ? win[L + idx] : x[idx];
 }
 
+// STAGE = span in LDS.  The span is stored de-interleaved by decimation phase, xs[phase][j] = X[base + j*M + phase]
+// (pitch P = ceil(span/M) + pad), so at tap k the 64 lanes of a wave -- 64 consecutive outputs, M samples
+// apart in the stream -- read 64 CONSECUTIVE LDS words of one phase row (with the plain layout a decimator
+// reads with a lane stride of M samples: 2M-way bank conflicts on ds_read_b64).  Taps come through the scalar
+// cache (k is wave-uniform): one LDS read and one FMA group per MAC.
 template <class K, bool STAGE>
 __global__ void __launch_bounds__(kFirBlock)
 fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                  const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
-                 typename K::T *__restrict__ y, size_t ny, int tile) {
+                 typename K::T *__restrict__ y, size_t ny, int tile, long long x_len) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -41,32 +48,67 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
     const int nt = (int)((ny - o0) < (size_t)tile ? (ny - o0) : (size_t)tile);
     const long long base = (long long)o0 * M - (L - 1);
     const int span = (nt - 1) * M + L;
+    const int pitch = (((tile - 1) * M + L + M - 1) / M) | 1;          // odd: phase rows start on different banks
 
     T *xs = reinterpret_cast<T *>(smem);
-    C *hs = reinterpret_cast<C *>(smem + (STAGE ? (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 : 0));
     if (STAGE) {
-        for (int i = threadIdx.x; i < span; i += kFirBlock) xs[i] = load_stream(win, x, base + i, L);
+        if (base >= 0 && base + span <= x_len) {       // block-uniform: the whole span lies inside x
+            const T *src = x + base;
+            if (M == 1) {
+                for (int i = threadIdx.x; i < span; i += kFirBlock) xs[i] = src[i];
+            } else {
+                for (int i = threadIdx.x; i < span; i += kFirBlock) {
+                    const int j = i / M, ph = i - j * M;
+                    xs[ph * pitch + j] = src[i];
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < span; i += kFirBlock) {
+                const int j = i / M, ph = i - j * M;
+                xs[ph * pitch + j] = load_stream(win, x, base + i, L);
+            }
+        }
+        __syncthreads();
     }
-    for (int k = threadIdx.x; k < L; k += kFirBlock) hs[k] = taps[k];
-    __syncthreads();
 
     T acc[kFirR];
 #pragma unroll
     for (int r = 0; r < kFirR; ++r) acc[r] = zero_of<T>();
 
-    // newest sample of output o sits at span offset o*M + (L-1)
-    for (int k = 0; k < L; ++k) {
-        const C hk = hs[k];
+    // newest sample of output o sits at span offset o*M + (L-1); tap k reads offset o*M + (L-1-k):
+    // phase (L-1-k) mod M, row index o + (L-1-k) div M.  Taps are fetched 8 at a time (one scalar load),
+    // a full tile (all 4 x 256 outputs exist) runs without per-output guards.
+    auto run = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        int ph = (L - 1) % M, jq = (L - 1) / M;
+        auto tap = [&](C hk, int k) {
+            if (STAGE) {
+                const T *row = xs + ph * pitch + jq + threadIdx.x;
 #pragma unroll
-        for (int r = 0; r < kFirR; ++r) {
-            const int o = threadIdx.x + r * kFirBlock;
-            if (o < nt) {
-                const int off = o * M + (L - 1) - k;
-                const T xv = STAGE ? xs[off] : load_stream(win, x, base + off, L);
-                acc[r] = mac(acc[r], xv, hk);
+                for (int r = 0; r < kFirR; ++r)
+                    if (FULL || (int)threadIdx.x + r * kFirBlock < nt) acc[r] = mac(acc[r], row[r * kFirBlock], hk);
+                if (--ph < 0) { ph = M - 1; --jq; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kFirR; ++r) {
+                    const int o = threadIdx.x + r * kFirBlock;
+                    if (FULL || o < nt)
+                        acc[r] = mac(acc[r], load_stream(win, x, base + (long long)o * M + (L - 1) - k, L), hk);
+                }
             }
+        };
+        int k = 0;
+        for (; k + 8 <= L; k += 8) {
+            C hk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hk[u] = taps[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tap(hk[u], k + u);
         }
-    }
+        for (; k < L; ++k) tap(taps[k], k);
+    };
+    if (nt == kFirR * kFirBlock) run(std::true_type{});
+    else run(std::false_type{});
 #pragma unroll
     for (int r = 0; r < kFirR; ++r) {
         const int o = threadIdx.x + r * kFirBlock;
@@ -76,42 +118,41 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
 
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
-                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
+                     size_t x_len) {
     using T = typename K::T;
-    using C = typename K::C;
     if (ny == 0) return YAGI_OK;
     if (L <= 0 || M <= 0) return fail(YAGI_ERR_INTERNAL, "fir_block: bad L/M");
-    // largest tile (<= R*256 outputs) whose span + taps fit the LDS budget
-    const size_t tap_bytes = (size_t)L * sizeof(C);
+    // largest tile (<= R*256 outputs) whose phase-split span fits the LDS budget
+    auto need = [&](int t) {
+        const size_t pitch = (size_t)((((long long)(t - 1) * M + L + M - 1) / M) | 1);
+        return (size_t)M * pitch * sizeof(T);
+    };
     int tile = kFirR * kFirBlock;
     bool stage = true;
-    while (tile >= 64) {
-        const size_t need = (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 + tap_bytes;
-        if (need <= kFirLdsBudget) break;
-        tile /= 2;
-    }
-    size_t lds;
-    if (tile < 64) {           // taps/span too large for LDS staging: stream from L2/HBM
-        if (tap_bytes > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "filter too long for this engine (%d taps)", L);
+    while (tile >= 64 && need(tile) > kFirLdsBudget) tile /= 2;
+    size_t lds = 0;
+    if (tile < 64) {           // span too large for LDS staging: stream from L2/HBM
         stage = false;
         tile = kFirR * kFirBlock;
-        lds = tap_bytes;
     } else {
-        lds = (((size_t)(tile - 1) * M + L) * sizeof(T) + 15) / 16 * 16 + tap_bytes;
+        lds = need(tile);
     }
     const size_t nblk = (ny + tile - 1) / tile;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    // x_len = samples readable at x (0 = unknown: the outputs' own span, ny*M)
+    const long long xl = (long long)(x_len ? x_len : ny * (size_t)M);
     if (stage)
-        fir_block_kernel<K, true><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile);
+        fir_block_kernel<K, true><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl);
     else
-        fir_block_kernel<K, false><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile);
+        fir_block_kernel<K, false><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
-template int launch_fir_block<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t);
-template int launch_fir_block<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t);
-template int launch_fir_block<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t);
+template int launch_fir_block<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t, size_t);
+template int launch_fir_block<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t, size_t);
+template int launch_fir_block<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t, size_t);
 
 // ---------------------------------------------------------------------------------------------
 // polyphase bank, all branches per pushed sample (interpolator form):

@@ -31,7 +31,8 @@ int launch_update_window(const T *old_win, const T *x, size_t n, int L, T *new_w
 // X index 0 = x[0].  i in [0, ny).  taps in natural order h[0..L).
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
-                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st);
+                     int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
+                     size_t x_len = 0 /* samples readable at x; 0 = ny*M */);
 
 // polyphase bank, all branches per input sample: y[n*nf + i] = scale * sum_k hb[i][k] X[n-k]
 // branch taps hb laid out [nf][Ls] in natural (newest-first) order.
