@@ -75,31 +75,35 @@ fft_lds_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__
 // Power-of-two N <= 8192 (other than 4096): a workgroup owns `nfr` consecutive transforms (so small
 // N still fills 256 lanes), radix-16/8/4/2 register butterflies, Stockham autosort through two LDS
 // buffers, twiddle table in LDS.  One HBM round trip: 16 B/point.
-template <int SIGN>
+// FRFAST (2 <= nfr <= 32 transforms per workgroup): transform slots are `pitch` = N + 32/nfr apart and the
+// passes map lanes transform-fastest, which makes every pass bank-conflict free (fft_radix.hpp); the
+// global <-> LDS copies stay butterfly-fastest (coalesced).  A partial last group computes its missing
+// transforms on whatever the LDS holds and does not store them.
+template <int SIGN, bool FRFAST>
 __global__ void __launch_bounds__(256)
 fft_pow2_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *__restrict__ out,
-                const float2 *__restrict__ tw, size_t batch, int nfr, int tw_in_lds) {
+                const float2 *__restrict__ tw, size_t batch, int nfr, int lgnfr, int pitch, int tw_in_lds) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *bufA = reinterpret_cast<float2 *>(smem);
-    float2 *bufB = bufA + (size_t)nfr * N;
+    float2 *bufB = bufA + (size_t)nfr * pitch;
     // the plan's table already carries the direction's sign (tw_is_forward = false below);
     // it is copied to LDS unless the transform itself needs the room (N = 8192)
     const float2 *twl = tw;
     if (tw_in_lds) {
-        float2 *t = bufB + (size_t)nfr * N;
+        float2 *t = bufB + (size_t)nfr * pitch;
         for (int e = threadIdx.x; e < N; e += 256) t[e] = tw[e];
         twl = t;
     }
-    for (size_t g = blockIdx.x; g * nfr < batch; g += gridDim.x) {
-        const size_t b0 = g * nfr;
-        const int nb = (int)((batch - b0) < (size_t)nfr ? (batch - b0) : (size_t)nfr);
-        const int total = nb * N;
-        __syncthreads();
-        for (int e = threadIdx.x; e < total; e += 256) bufA[e] = in[b0 * N + e];
-        __syncthreads();
-        float2 *res = lds_fft_pow2<SIGN>(bufA, bufB, N, nb, plan, twl, 1, false);
-        for (int e = threadIdx.x; e < total; e += 256) out[b0 * N + e] = res[e];
-    }
+    const int lgN = 31 - __builtin_clz((unsigned)N);
+    const size_t b0 = (size_t)blockIdx.x * nfr;
+    const int nb = (int)((batch - b0) < (size_t)nfr ? (batch - b0) : (size_t)nfr);
+    const int total = nb * N;
+    const float2 *src = in + b0 * N;
+    float2 *dst = out + b0 * N;
+    for (int e = threadIdx.x; e < total; e += 256) bufA[(e >> lgN) * pitch + (e & (N - 1))] = src[e];
+    __syncthreads();
+    const float2 *res = lds_fft_pow2<SIGN, FRFAST>(bufA, bufB, N, FRFAST ? nfr : nb, plan, twl, 1, false, pitch, lgnfr);
+    for (int e = threadIdx.x; e < total; e += 256) dst[e] = res[(e >> lgN) * pitch + (e & (N - 1))];
 }
 
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
@@ -119,19 +123,30 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
     }
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
     if (p.n >= 2 && (p.n & (p.n - 1)) == 0) {
-        int nfr = 4096 / p.n;
+        // 2048 points per workgroup (<= 32 transforms) for N <= 2048: 2 x 16 KiB of LDS + table, 3-4 workgroups per CU
+        int nfr = (p.n <= 2048 ? 2048 : 4096) / p.n;
         if (nfr < 1) nfr = 1;
+        if (nfr > 32) nfr = 32;
+        const bool frfast = nfr >= 2;
+        int lgnfr = 0;
+        while ((1 << lgnfr) < nfr) ++lgnfr;
+        const int pitch = frfast ? frfast_pitch(p.n, nfr) : p.n;
         const int tw_in_lds = p.n <= 4096 ? 1 : 0;
-        const size_t lds2 = (2 * (size_t)nfr * p.n + (tw_in_lds ? (size_t)p.n : 0)) * sizeof(float2);
+        const size_t lds2 = (2 * (size_t)nfr * pitch + (tw_in_lds ? (size_t)p.n : 0)) * sizeof(float2);
         const size_t groups = (batch + nfr - 1) / nfr;
-        const unsigned grid2 = (unsigned)(groups < 32768 ? groups : 32768);
-        const void *fn = p.dir == YAGI_FFT_FORWARD ? reinterpret_cast<const void *>(fft_pow2_kernel<-1>)
-                                                   : reinterpret_cast<const void *>(fft_pow2_kernel<+1>);
+        if (groups > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+        const unsigned grid2 = (unsigned)groups;
+        const bool fwd = p.dir == YAGI_FFT_FORWARD;
+        const void *fn = frfast ? (fwd ? reinterpret_cast<const void *>(fft_pow2_kernel<-1, true>)
+                                       : reinterpret_cast<const void *>(fft_pow2_kernel<+1, true>))
+                                : (fwd ? reinterpret_cast<const void *>(fft_pow2_kernel<-1, false>)
+                                       : reinterpret_cast<const void *>(fft_pow2_kernel<+1, false>));
         if (lds2 > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (p.dir == YAGI_FFT_FORWARD)
-            fft_pow2_kernel<-1><<<grid2, 256, lds2, st>>>(p.n, make_pow2_plan(p.n), fin, fout, tw, batch, nfr, tw_in_lds);
-        else
-            fft_pow2_kernel<+1><<<grid2, 256, lds2, st>>>(p.n, make_pow2_plan(p.n), fin, fout, tw, batch, nfr, tw_in_lds);
+        const Pow2Plan plan = make_pow2_plan(p.n);
+#define YG_POW2_LAUNCH(S, F) fft_pow2_kernel<S, F><<<grid2, 256, lds2, st>>>(p.n, plan, fin, fout, tw, batch, nfr, lgnfr, pitch, tw_in_lds)
+        if (frfast) { if (fwd) YG_POW2_LAUNCH(-1, true); else YG_POW2_LAUNCH(+1, true); }
+        else { if (fwd) YG_POW2_LAUNCH(-1, false); else YG_POW2_LAUNCH(+1, false); }
+#undef YG_POW2_LAUNCH
         YG_LAUNCH_CHECK();
         return YAGI_OK;
     }
