@@ -51,7 +51,7 @@ def test_fft_config(ya):
     assert np.array_equal(ya.Fft(1, ya.Direction.Forward).run(np.complex64([3 - 2j])), np.complex64([3 - 2j]))
 
 
-@pytest.mark.parametrize("n", [64, 256, 1000, 1024, 2048, 3125, 4096, 8192, 4093])
+@pytest.mark.parametrize("n", [2, 16, 32, 64, 128, 256, 512, 1000, 1024, 2048, 3125, 4096, 8192, 4093])
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_vs_f64_definition(ya, oracle, n, direction):
     """parity unpinned by the reference above N = 509; pinned by the definition (f64 DFT)."""

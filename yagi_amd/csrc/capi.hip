@@ -312,15 +312,22 @@ static void factorize(int n, int *fac, int &nfac) {
     if (n > 1) fac[nfac++] = n;
 }
 
-static int make_twiddles(int n, int dir, DevBuf &buf) {
-    std::vector<cf32> t((size_t)n);
+// W_n^m, m in [0,n); with half_too the W_{n/2} table follows at offset n (the 8192-point kernel runs two
+// 4096-point transforms and needs both)
+static int make_twiddles(int n, int dir, DevBuf &buf, bool half_too = false) {
+    std::vector<cf32> t((size_t)n + (half_too ? (size_t)n / 2 : 0));
     const double s = (dir == YAGI_FFT_FORWARD) ? -1.0 : 1.0;
     for (int m = 0; m < n; ++m) {
         const double a = s * 2.0 * M_PI * (double)m / (double)n;
         t[m] = cf32{(float)std::cos(a), (float)std::sin(a)};
     }
-    YG_TRY(buf.alloc((size_t)n * sizeof(cf32)));
-    return upload(buf.p, t.data(), (size_t)n * sizeof(cf32), nullptr);
+    if (half_too)
+        for (int m = 0; m < n / 2; ++m) {
+            const double a = s * 2.0 * M_PI * (double)m / (double)(n / 2);
+            t[(size_t)n + m] = cf32{(float)std::cos(a), (float)std::sin(a)};
+        }
+    YG_TRY(buf.alloc(t.size() * sizeof(cf32)));
+    return upload(buf.p, t.data(), t.size() * sizeof(cf32), nullptr);
 }
 
 static int fft_plan_init(FftPlan &p, size_t n, int dir) {
@@ -331,7 +338,7 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     p.d.n = (int)n;
     p.d.dir = dir;
     factorize((int)n, p.d.fac, p.d.nfac);
-    YG_TRY(make_twiddles((int)n, dir, p.tw));
+    YG_TRY(make_twiddles((int)n, dir, p.tw, n == 8192));
     p.d.tw = p.tw.as<cf32>();
     return YAGI_OK;
 }

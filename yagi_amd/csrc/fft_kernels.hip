@@ -30,6 +30,117 @@ fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// N = 256 M, M in {1, 2, 4, 8} (256 .. 2048): the 4096-point scheme with a radix-M last pass (M = 1: none).
+// A workgroup owns 16/M transforms (4096 points, 16 per lane); a transform is spread over 16 M lanes.
+//   pass 1  lane b (< 16M)        : v[a]  = x[16M a + b]        -> Z_c[b] = W_N^{bc} sum_a v[a] W16^{ac}
+//   pass 2  lane (c, b') = cM + b': v[a'] = Z_c[M a' + b']      -> U_{c,c'}[b'] = W_N^{16 b' c'} sum_a' ...
+//   pass 3  lane u, pairs p = u + 16M i (p = c + 16c', i < 16/M): X[p + 256 d'] = sum_b' U_p[b'] W_M^{b' d'}
+// Global loads and stores are runs of 16M consecutive points per transform.  LDS layouts (float2):
+//   exchange 1: [transform][c][b], row stride 17M  (= M mod 32: pass-2 reads hit distinct banks)
+//   exchange 2: [transform][b'][p], row stride 256 + 16/M (pass-2 writes hit distinct banks)
+// M = 16 is fft4096_passes (fft_core.hpp).  Lanes of transforms past the end of the batch load zeros and
+// skip their stores.
+// ---------------------------------------------------------------------------------------------
+template <int SIGN, int M>
+__global__ void __launch_bounds__(256)
+fft_n256m_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
+                 size_t batch) {
+    constexpr int N = 256 * M, LT = 16 * M, B = 16 / M;          // points, lanes per transform, transforms per WG
+    constexpr int S1 = 17 * M, T1 = 16 * S1;                    // exchange 1: row stride, transform stride
+    constexpr int S2 = 256 + 16 / M, T2 = M * S2;               // exchange 2
+    static_assert(B * T1 <= kFft4096LdsFloat2 && B * T2 <= kFft4096LdsFloat2, "LDS layout");
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x, tr = t / LT, u = t % LT;
+    const size_t g = (size_t)blockIdx.x * B + tr;
+    const bool live = g < batch;
+    const float2 *src = in + g * N;
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = live ? src[LT * a + u] : make_float2(0.f, 0.f);
+    // ---- pass 1 ----
+    dft16<SIGN>(v);
+    {
+        float2 w[16];
+        twiddle_powers(w, tw, u, (unsigned)(N - 1));             // W_N^{u c}: u c < N, the mask never wraps
+        float2 *e1 = lds + tr * T1 + u;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul(z, w[c]);
+            e1[c * S1] = z;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2 ----
+    {
+        const unsigned c = u / M, bp = u % M;
+        const float2 *e1 = lds + tr * T1 + c * S1 + bp;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = e1[M * a];
+        __syncthreads();                                         // exchange-1 reads done before the buffer is reused
+        dft16<SIGN>(v);
+        float2 w[16];
+        twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));      // W_{16M}^{b' c'} = W_N^{16 b' c'}
+        float2 *e2 = lds + tr * T2 + bp * S2 + c;
+#pragma unroll
+        for (int cp = 0; cp < 16; ++cp) {
+            float2 z = v[dft16_pos(cp)];
+            if (cp) z = cmul(z, w[cp]);
+            e2[16 * cp] = z;
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: 16/M radix-M butterflies per lane ----
+    {
+        const float2 *e2 = lds + tr * T2 + u;
+        float2 *dst = out + g * N + u;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            float2 r[M];
+#pragma unroll
+            for (int bp = 0; bp < M; ++bp) r[bp] = e2[bp * S2 + LT * i];
+            if constexpr (M > 1) dftR<M, SIGN>(r);
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < M; ++d) dst[LT * i + 256 * d] = r[d];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// N = 8192 = 2 x 4096 (decimation in time): one 16-byte load per lane brings an even and an odd sample,
+// the two 4096-point transforms run back to back in registers (fft4096_passes_to_regs), and the last
+// radix-2 stage X[k] = E[k] + W_8192^k O[k], X[k + 4096] = E[k] - W_8192^k O[k] writes both halves
+// coalesced.  `tw` = W_8192 table followed by the W_4096 table (capi.hip: make_twiddles half_too).
+// ---------------------------------------------------------------------------------------------
+template <int SIGN>
+__global__ void __launch_bounds__(256)
+fft8192_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(in + (size_t)blockIdx.x * 8192);
+    const float2 *tw4096 = tw + 8192;
+    float2 e[16], o[16];
+#pragma unroll
+    for (unsigned a = 0; a < 16; ++a) {
+        const float4 q = src[256u * a + t];
+        e[a] = make_float2(q.x, q.y);
+        o[a] = make_float2(q.z, q.w);
+    }
+    fft4096_passes_to_regs<SIGN>(e, lds, tw4096);
+    fft4096_passes_to_regs<SIGN>(o, lds, tw4096);
+    float2 *dst = out + (size_t)blockIdx.x * 8192;
+#pragma unroll
+    for (unsigned d = 0; d < 16; ++d) {
+        const unsigned k = t + 256u * d;
+        const float2 p = cmul(o[d], tw[k]);
+        dst[k] = cadd(e[d], p);
+        dst[k + 4096] = csub(e[d], p);
+    }
+}
+
 // Stockham pass structure (Ns = product of the radices already applied, T = N / R):
 //   butterfly j in [0,T), k = j mod Ns, output q in [0,R):
 //     out[(j / Ns) * Ns * R + k + q * Ns] = sum_r in[j + r*T] * W_N^{ r * (k*N/(Ns*R) + q*N/R) }
@@ -122,6 +233,33 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         return YAGI_OK;
     }
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
+    if (p.n == 8192) {
+        if (batch > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+        if (p.dir == YAGI_FFT_FORWARD) fft8192_kernel<-1><<<(unsigned)batch, 256, 0, st>>>(fin, fout, tw);
+        else fft8192_kernel<+1><<<(unsigned)batch, 256, 0, st>>>(fin, fout, tw);
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
+    if (p.n == 256 || p.n == 512 || p.n == 1024 || p.n == 2048) {
+        constexpr int kPts = 4096;
+        const size_t per_wg = (size_t)(kPts / p.n);
+        const size_t groups = (batch + per_wg - 1) / per_wg;
+        if (groups > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+        const unsigned grid = (unsigned)groups;
+        const bool fwd = p.dir == YAGI_FFT_FORWARD;
+#define YG_N256M(MM)                                                                                 \
+    do {                                                                                             \
+        if (fwd) fft_n256m_kernel<-1, MM><<<grid, 256, 0, st>>>(fin, fout, tw, batch);               \
+        else fft_n256m_kernel<+1, MM><<<grid, 256, 0, st>>>(fin, fout, tw, batch);                   \
+    } while (0)
+        if (p.n == 256) YG_N256M(1);
+        else if (p.n == 512) YG_N256M(2);
+        else if (p.n == 1024) YG_N256M(4);
+        else YG_N256M(8);
+#undef YG_N256M
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
     if (p.n >= 2 && (p.n & (p.n - 1)) == 0) {
         // 2048 points per workgroup (<= 32 transforms) for N <= 2048: 2 x 16 KiB of LDS + table, 3-4 workgroups per CU
         int nfr = (p.n <= 2048 ? 2048 : 4096) / p.n;
