@@ -10,6 +10,7 @@
 // standalone dotprod kernel over (window, taps); block calls run the FIR kernels and then
 // advance the window.  clone() copies the device state; reset() zeroes it.
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "kernels.hpp"
@@ -301,12 +302,19 @@ struct FftPlan {
     FftPlanDev d;
     DevBuf tw;
     Workspace ws;
+    DevBuf bs_w, bs_bf, bs_twf, bs_twb, bs_scratch;      // Bluestein resources (sizes with a large prime factor)
 };
 
+// radix list of the mixed-radix kernel: the power of two in as few passes as radix <= 16 allows (bits spread
+// evenly), then the odd primes in ascending order (3, 5, 7 have register butterflies, larger ones direct sums)
 static void factorize(int n, int *fac, int &nfac) {
     nfac = 0;
-    while (n % 4 == 0) { fac[nfac++] = 4; n /= 4; }
-    while (n % 2 == 0) { fac[nfac++] = 2; n /= 2; }
+    int lg = 0;
+    while (n % 2 == 0) { ++lg; n /= 2; }
+    if (lg) {
+        const int np = (lg + 3) / 4;
+        for (int i = 0; i < np; ++i) fac[nfac++] = 1 << (lg / np + (i < lg % np ? 1 : 0));
+    }
     for (int p = 3; (long long)p * p <= n; p += 2)
         while (n % p == 0) { fac[nfac++] = p; n /= p; }
     if (n > 1) fac[nfac++] = n;
@@ -340,6 +348,49 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     factorize((int)n, p.d.fac, p.d.nfac);
     YG_TRY(make_twiddles((int)n, dir, p.tw, n == 8192));
     p.d.tw = p.tw.as<cf32>();
+    // A prime factor p costs O(n p) per transform in the mixed-radix kernel's direct-sum pass; beyond 89 (measured crossover; and
+    // while the 2n-1 point convolution fits the largest power-of-two kernel) Bluestein's chirp-z form is used:
+    //   X[k] = w[k] sum_j (x[j] w[j]) conj(w[k-j]),  w[k] = e^{-+ j pi k^2 / n}
+    int maxp = 1;
+    for (int i = 0; i < p.d.nfac; ++i) maxp = p.d.fac[i] > maxp ? p.d.fac[i] : maxp;
+    static const int bs_minp = getenv("YAGI_HIP_BLUESTEIN_MIN_PRIME") ? atoi(getenv("YAGI_HIP_BLUESTEIN_MIN_PRIME")) : 89;
+    if (maxp > bs_minp && 2 * n - 1 <= (size_t)kFftMaxLds) {
+        int m = 1;
+        while ((size_t)m < 2 * n - 1) m *= 2;
+        if (m < 256) m = 256;
+        const double sgn = (dir == YAGI_FFT_FORWARD) ? -1.0 : 1.0;
+        std::vector<cf32> w(n), b((size_t)m, cf32{0.f, 0.f});
+        for (size_t k = 0; k < n; ++k) {
+            const unsigned long long k2 = ((unsigned long long)k * k) % (2ull * n);      // exact phase index
+            const double a = sgn * M_PI * (double)k2 / (double)n;
+            w[k] = cf32{(float)std::cos(a), (float)std::sin(a)};
+            const cf32 cw{w[k].re, -w[k].im};
+            b[k] = cw;
+            if (k) b[(size_t)m - k] = cw;
+        }
+        YG_TRY(p.bs_w.alloc(n * sizeof(cf32)));
+        YG_TRY(upload(p.bs_w.p, w.data(), n * sizeof(cf32), nullptr));
+        YG_TRY(make_twiddles(m, YAGI_FFT_FORWARD, p.bs_twf, m == 8192));
+        YG_TRY(make_twiddles(m, YAGI_FFT_BACKWARD, p.bs_twb, m == 8192));
+        const int chunk = (1 << 21) / m;                       // 2 x 16 MiB of scratch
+        YG_TRY(p.bs_scratch.alloc(2 * (size_t)chunk * m * sizeof(cf32)));
+        YG_TRY(p.bs_bf.alloc((size_t)m * sizeof(cf32)));
+        // FFT_m of the chirp filter by the device transform itself
+        FftPlanDev f;
+        f.n = m;
+        f.dir = YAGI_FFT_FORWARD;
+        f.tw = p.bs_twf.as<cf32>();
+        YG_TRY(upload(p.bs_scratch.p, b.data(), (size_t)m * sizeof(cf32), nullptr));
+        YG_TRY(launch_fft_batch(f, p.bs_scratch.as<cf32>(), p.bs_bf.as<cf32>(), 1, nullptr));
+        YG_HIP(hipStreamSynchronize(nullptr));
+        p.d.bs_m = m;
+        p.d.bs_w = p.bs_w.as<cf32>();
+        p.d.bs_bf = p.bs_bf.as<cf32>();
+        p.d.bs_twf = p.bs_twf.as<cf32>();
+        p.d.bs_twb = p.bs_twb.as<cf32>();
+        p.d.bs_scratch = p.bs_scratch.as<cf32>();
+        p.d.bs_chunk = chunk;
+    }
     return YAGI_OK;
 }
 

@@ -5,10 +5,11 @@
 //   fft4096_kernel   config C3 (4096-pt x 65 536): one workgroup per transform, data makes one
 //                    HBM round trip (64 KiB per transform = 16 B/point), everything else in
 //                    registers + 34 KiB LDS (fft_core.hpp).
-//   fft_lds_kernel   any N <= 8192: Stockham autosort passes in LDS over the plan's factor list;
-//                    each lane produces ONE output of a radix-R butterfly per pass by a direct
-//                    R-term sum with exact table twiddles (index arithmetic mod N), so every
-//                    radix, prime or not, takes the same code path (O(N * sum(R)) work).
+//   fft_n256m_kernel, fft8192_kernel   the same register scheme for 256..2048 and 8192
+//   fft_pow2_kernel  other powers of two (N <= 128): LDS-staged register Stockham passes
+//   fft_mixed_kernel any other N <= 8192: mixed-radix Stockham passes in LDS over the plan's factor
+//                    list, register butterflies for radix 16/8/4/2/3/5/7, direct R-term sums (exact
+//                    table twiddles, index arithmetic mod N) for any other prime factor.
 #include "fft_radix.hpp"
 #include "kernels.hpp"
 
@@ -141,46 +142,43 @@ fft8192_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const fl
     }
 }
 
-// Stockham pass structure (Ns = product of the radices already applied, T = N / R):
-//   butterfly j in [0,T), k = j mod Ns, output q in [0,R):
-//     out[(j / Ns) * Ns * R + k + q * Ns] = sum_r in[j + r*T] * W_N^{ r * (k*N/(Ns*R) + q*N/R) }
+// Mixed radix, any N <= 8192 that is not a power of two: a workgroup owns nfr = 2048/N (>= 1) consecutive
+// transforms; Stockham autosort passes over the plan's factor list (radices 16/8/4/2/3/5/7 as register
+// butterflies, any other prime by direct sums), two LDS buffers.  One HBM round trip: 16 B/point.
+template <int SIGN>
 __global__ void __launch_bounds__(256)
-fft_lds_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__ out, size_t batch) {
+fft_mixed_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__ out, size_t batch, int nfr) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *bufA = reinterpret_cast<float2 *>(smem);
-    float2 *bufB = bufA + p.n;
-    const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
     const int N = p.n;
-    for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
-        for (int i = threadIdx.x; i < N; i += blockDim.x) bufA[i] = in[b * N + i];
-        __syncthreads();
-        float2 *src = bufA, *dst = bufB;
-        int Ns = 1;
-        for (int f = 0; f < p.nfac; ++f) {
-            const int R = p.fac[f];
-            const int T = N / R;
-            const int tw_k = N / (Ns * R);        // W_{Ns*R} = W_N^{tw_k}
-            for (int idx = threadIdx.x; idx < N; idx += blockDim.x) {
-                const int q = idx / T, j = idx - q * T;
-                const int k = j % Ns;
-                // step = (k*tw_k + q*T) mod N, kept < N; the twiddle index advances by `step` per term
-                int step = (int)(((long long)k * tw_k + (long long)q * T) % N);
-                int m = 0;
-                float2 acc = src[j];
-                for (int r = 1; r < R; ++r) {
-                    m += step;
-                    if (m >= N) m -= N;
-                    acc = cadd(acc, cmul(src[j + r * T], tw[m]));
-                }
-                dst[(j / Ns) * Ns * R + k + q * Ns] = acc;
-            }
-            __syncthreads();
-            float2 *tmp = src; src = dst; dst = tmp;
-            Ns *= R;
+    float2 *bufA = reinterpret_cast<float2 *>(smem);
+    float2 *bufB = bufA + (size_t)nfr * N;
+    const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
+    const size_t b0 = (size_t)blockIdx.x * nfr;
+    const int nb = (int)((batch - b0) < (size_t)nfr ? (batch - b0) : (size_t)nfr);
+    const int total = nb * N;
+    const float2 *gsrc = in + b0 * N;
+    float2 *gdst = out + b0 * N;
+    for (int e = threadIdx.x; e < total; e += 256) bufA[e] = gsrc[e];
+    __syncthreads();
+    float2 *src = bufA, *dst = bufB;
+    int Ns = 1;
+    for (int f = 0; f < p.nfac; ++f) {
+        const int R = p.fac[f];
+        switch (R) {
+            case 16: stockham_pass_any<16, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 8: stockham_pass_any<8, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 7: stockham_pass_any<7, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 5: stockham_pass_any<5, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 4: stockham_pass_any<4, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 3: stockham_pass_any<3, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 2: stockham_pass_any<2, SIGN>(src, dst, N, Ns, nb, tw); break;
+            default: stockham_pass_direct(src, dst, N, R, Ns, nb, tw); break;
         }
-        for (int i = threadIdx.x; i < N; i += blockDim.x) out[b * N + i] = src[i];
         __syncthreads();
+        float2 *tmp = src; src = dst; dst = tmp;
+        Ns *= R;
     }
+    for (int e = threadIdx.x; e < total; e += 256) gdst[e] = src[e];
 }
 
 // Power-of-two N <= 8192 (other than 4096): a workgroup owns `nfr` consecutive transforms (so small
@@ -217,6 +215,61 @@ fft_pow2_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *__r
     for (int e = threadIdx.x; e < total; e += 256) dst[e] = res[(e >> lgN) * pitch + (e & (N - 1))];
 }
 
+// Bluestein element-wise stages: a[k] = x[k] w[k] zero-padded to m;  X[k] = w[k] y[k] / m
+__global__ void __launch_bounds__(256)
+bluestein_pre_kernel(const float2 *__restrict__ x, const float2 *__restrict__ w, int n, int m, size_t nb,
+                     float2 *__restrict__ a) {
+    const size_t total = nb * (size_t)m;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / m;
+        const int k = (int)(e - b * m);
+        a[e] = k < n ? cmul(x[b * n + k], w[k]) : make_float2(0.f, 0.f);
+    }
+}
+__global__ void __launch_bounds__(256)
+bluestein_post_kernel(const float2 *__restrict__ y, const float2 *__restrict__ w, int n, int m, size_t nb,
+                      float2 *__restrict__ X) {
+    const size_t total = nb * (size_t)n;
+    const float inv = 1.0f / (float)m;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / n;
+        const int k = (int)(e - b * n);
+        X[e] = cscale(cmul(y[b * m + k], w[k]), inv);
+    }
+}
+__global__ void __launch_bounds__(256)
+bluestein_mul_kernel(float2 *__restrict__ f, const float2 *__restrict__ bf, int m, size_t nb) {
+    const size_t total = nb * (size_t)m;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        f[e] = cmul(f[e], bf[e & (size_t)(m - 1)]);
+}
+
+static int launch_fft_bluestein(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    const int m = p.bs_m;
+    FftPlanDev fwd, bwd;
+    fwd.n = bwd.n = m;
+    fwd.dir = YAGI_FFT_FORWARD;
+    bwd.dir = YAGI_FFT_BACKWARD;
+    fwd.tw = p.bs_twf;
+    bwd.tw = p.bs_twb;
+    float2 *s0 = reinterpret_cast<float2 *>(p.bs_scratch), *s1 = s0 + (size_t)p.bs_chunk * m;
+    const float2 *w = reinterpret_cast<const float2 *>(p.bs_w);
+    for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.bs_chunk) {
+        const size_t nb = (batch - b0) < (size_t)p.bs_chunk ? (batch - b0) : (size_t)p.bs_chunk;
+        size_t g = (nb * (size_t)m + 255) / 256;
+        if (g > 16384) g = 16384;
+        bluestein_pre_kernel<<<(unsigned)g, 256, 0, st>>>(reinterpret_cast<const float2 *>(in) + b0 * p.n, w, p.n, m, nb, s0);
+        YG_LAUNCH_CHECK();
+        YG_TRY(launch_fft_batch(fwd, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), nb, st));
+        bluestein_mul_kernel<<<(unsigned)g, 256, 0, st>>>(s1, reinterpret_cast<const float2 *>(p.bs_bf), m, nb);
+        YG_LAUNCH_CHECK();
+        YG_TRY(launch_fft_batch(bwd, reinterpret_cast<const cf32 *>(s1), reinterpret_cast<cf32 *>(s0), nb, st));
+        bluestein_post_kernel<<<(unsigned)g, 256, 0, st>>>(s0, w, p.n, m, nb, reinterpret_cast<float2 *>(out) + b0 * p.n);
+        YG_LAUNCH_CHECK();
+    }
+    return YAGI_OK;
+}
+
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     if (batch == 0) return YAGI_OK;
     const float2 *fin = reinterpret_cast<const float2 *>(in);
@@ -233,6 +286,7 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         return YAGI_OK;
     }
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
+    if (p.bs_m) return launch_fft_bluestein(p, in, out, batch, st);
     if (p.n == 8192) {
         if (batch > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
         if (p.dir == YAGI_FFT_FORWARD) fft8192_kernel<-1><<<(unsigned)batch, 256, 0, st>>>(fin, fout, tw);
@@ -288,19 +342,19 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         YG_LAUNCH_CHECK();
         return YAGI_OK;
     }
-    const size_t lds = 2 * (size_t)p.n * sizeof(float2);
-    const unsigned grid = (unsigned)(batch < 16384 ? batch : 16384);
-    int threads = 256;
-    if (p.n < 256) threads = ((p.n + 63) / 64) * 64;
+    int nfr = 2048 / p.n;
+    if (nfr < 1) nfr = 1;
+    const size_t lds = 2 * (size_t)nfr * p.n * sizeof(float2);
+    const size_t groups = (batch + nfr - 1) / nfr;
+    if (groups > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+    const bool fwd = p.dir == YAGI_FFT_FORWARD;
     if (lds > 64 * 1024) {
-        static bool raised = false;            // one-time opt-in to >64 KiB dynamic LDS
-        if (!raised) {
-            YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        const void *fn = fwd ? reinterpret_cast<const void *>(fft_mixed_kernel<-1>)
+                             : reinterpret_cast<const void *>(fft_mixed_kernel<+1>);
+        YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    fft_lds_kernel<<<grid, threads, lds, st>>>(p, fin, fout, batch);
+    if (fwd) fft_mixed_kernel<-1><<<(unsigned)groups, 256, lds, st>>>(p, fin, fout, batch, nfr);
+    else fft_mixed_kernel<+1><<<(unsigned)groups, 256, lds, st>>>(p, fin, fout, batch, nfr);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }

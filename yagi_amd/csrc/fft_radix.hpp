@@ -32,9 +32,54 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
     v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
 }
 
+// Odd-prime butterflies, natural order in and out.  X[k] and X[R-k] share their cosine part m_k and differ in the
+// sign of the sine part n_k:  X[k] = m_k -+ i n_k, X[R-k] = m_k +- i n_k  (upper sign: forward).
+template <int SIGN>
+__device__ __forceinline__ void dft3(float2 (&v)[3]) {
+    const float s1 = 0.86602540378443865f;                                  // sin(2 pi / 3)
+    const float2 t1 = cadd(v[1], v[2]), u1 = csub(v[1], v[2]);
+    const float2 m1 = f2(tov(v[0]) - 0.5f * tov(t1));
+    v[0] = cadd(v[0], t1);
+    addsub_rot<SIGN>(m1, cscale(u1, s1), v[1], v[2]);
+}
+template <int SIGN>
+__device__ __forceinline__ void dft5(float2 (&v)[5]) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;     // cos(2 pi k / 5)
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;      // sin(2 pi k / 5)
+    const v2f a = tov(v[0]);
+    const v2f t1 = tov(v[1]) + tov(v[4]), t2 = tov(v[2]) + tov(v[3]);
+    const v2f u1 = tov(v[1]) - tov(v[4]), u2 = tov(v[2]) - tov(v[3]);
+    const v2f m1 = a + c1 * t1 + c2 * t2, m2 = a + c2 * t1 + c1 * t2;
+    const v2f n1 = s1 * u1 + s2 * u2, n2 = s2 * u1 - s1 * u2;
+    v[0] = f2(a + t1 + t2);
+    addsub_rot<SIGN>(f2(m1), f2(n1), v[1], v[4]);
+    addsub_rot<SIGN>(f2(m2), f2(n2), v[2], v[3]);
+}
+template <int SIGN>
+__device__ __forceinline__ void dft7(float2 (&v)[7]) {
+    const float c1 = 0.62348980185873353f, c2 = -0.22252093395631440f, c3 = -0.90096886790241913f;   // cos(2 pi k / 7)
+    const float s1 = 0.78183148246802981f, s2 = 0.97492791218182361f, s3 = 0.43388373911755812f;    // sin(2 pi k / 7)
+    const v2f a = tov(v[0]);
+    const v2f t1 = tov(v[1]) + tov(v[6]), t2 = tov(v[2]) + tov(v[5]), t3 = tov(v[3]) + tov(v[4]);
+    const v2f u1 = tov(v[1]) - tov(v[6]), u2 = tov(v[2]) - tov(v[5]), u3 = tov(v[3]) - tov(v[4]);
+    const v2f m1 = a + c1 * t1 + c2 * t2 + c3 * t3;
+    const v2f m2 = a + c2 * t1 + c3 * t2 + c1 * t3;
+    const v2f m3 = a + c3 * t1 + c1 * t2 + c2 * t3;
+    const v2f n1 = s1 * u1 + s2 * u2 + s3 * u3;
+    const v2f n2 = s2 * u1 - s3 * u2 - s1 * u3;
+    const v2f n3 = s3 * u1 - s1 * u2 + s2 * u3;
+    v[0] = f2(a + t1 + t2 + t3);
+    addsub_rot<SIGN>(f2(m1), f2(n1), v[1], v[6]);
+    addsub_rot<SIGN>(f2(m2), f2(n2), v[2], v[5]);
+    addsub_rot<SIGN>(f2(m3), f2(n3), v[3], v[4]);
+}
+
 template <int R, int SIGN>
 __device__ __forceinline__ void dftR(float2 (&v)[R]) {
     if constexpr (R == 2) dft2<SIGN>(v[0], v[1]);
+    else if constexpr (R == 3) dft3<SIGN>(v);
+    else if constexpr (R == 5) dft5<SIGN>(v);
+    else if constexpr (R == 7) dft7<SIGN>(v);
     else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 8) dft8<SIGN>(v);
     else {
@@ -125,6 +170,58 @@ __device__ __forceinline__ float2 *lds_fft_pow2(float2 *src, float2 *dst, int N,
         Ns *= R;
     }
     return src;
+}
+
+// Mixed-radix form of stockham_pass: N, Ns, T = N/R arbitrary (index math by division), table twiddles
+// W_N^m with the direction's sign already applied.  R in {2,3,4,5,7,8,16}: register butterfly.
+template <int R, int SIGN>
+__device__ __forceinline__ void stockham_pass_any(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                  int N, int Ns, int nfr, const float2 *__restrict__ twl) {
+    const int T = N / R;
+    const int total = T * nfr;
+    const int tw_k = N / (Ns * R);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int fr = e / T, j = e - fr * T;
+        const int k = j % Ns;
+        const float2 *s = src + fr * N + j;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = s[r * T];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], twl[k * r * tw_k]);
+        }
+        dftR<R, SIGN>(v);
+        float2 *d = dst + fr * N + (j - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) d[q * Ns] = v[dftR_pos<R>(q)];
+    }
+}
+
+// Any other radix (primes >= 11): every lane produces ONE output of a butterfly by a direct R-term sum with
+// exact table twiddles (index arithmetic mod N): O(N R) work for this pass.
+__device__ __forceinline__ void stockham_pass_direct(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                     int N, int R, int Ns, int nfr,
+                                                     const float2 *__restrict__ twl) {
+    const int T = N / R;
+    const int tw_k = N / (Ns * R);                 // W_{Ns*R} = W_N^{tw_k}
+    const int total = N * nfr;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int fr = e / N, idx = e - fr * N;
+        const int q = idx / T, j = idx - q * T;
+        const int k = j % Ns;
+        // step = (k*tw_k + q*T) mod N, kept < N; the twiddle index advances by `step` per term
+        const int step = (int)(((long long)k * tw_k + (long long)q * T) % N);
+        const float2 *s = src + fr * N;
+        int m = 0;
+        float2 acc = s[j];
+        for (int r = 1; r < R; ++r) {
+            m += step;
+            if (m >= N) m -= N;
+            acc = cadd(acc, cmul(s[j + r * T], twl[m]));
+        }
+        dst[fr * N + (j / Ns) * Ns * R + k + q * Ns] = acc;
+    }
 }
 
 // LDS pitch (float2) of one transform slot when nfr = 2^k <= 32 transforms of <= N points share a pass (FRFAST)

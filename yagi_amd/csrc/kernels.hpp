@@ -94,6 +94,14 @@ struct FftPlanDev {
     int nfac = 0;
     int fac[16] = {0};
     const cf32 *tw = nullptr;        // W_n^m, m in [0,n), sign per direction
+    // Bluestein (chirp-z) form for sizes with a large prime factor: X = w . IFFT_m(FFT_m(x . w) . FFT_m(b)) / m
+    int bs_m = 0;                    // 0 = not used; else the power-of-two convolution length >= 2n-1
+    const cf32 *bs_w = nullptr;      // chirp w[k] = e^{-+ j pi k^2 / n}, k < n
+    const cf32 *bs_bf = nullptr;     // FFT_m of the circular chirp filter conj(w[|k|])
+    const cf32 *bs_twf = nullptr;    // W_m tables, forward / backward (8192: followed by the W_4096 table)
+    const cf32 *bs_twb = nullptr;
+    cf32 *bs_scratch = nullptr;      // 2 * bs_chunk * m points
+    int bs_chunk = 0;                // transforms per pass through the scratch
 };
 constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st);
