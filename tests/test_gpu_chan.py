@@ -197,3 +197,68 @@ def test_firpfbch2_sharded_driver_rccl_world1(ya, oracle):
         assert rel_l2(y.cpu().numpy(), want) <= 1e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_config_c4_firpfbch_64ch_full_size(ya, oracle):
+    """BASELINE config C4 at full size: M 64, m 8 (p = 16), 2^26 complex samples generated on the device (runs of
+    256 frames per column group: 16 half tiles each, the prefetch path).  Sampled frames -- first frames, every
+    kind of run / tile boundary, the last frame -- against the oracle run on the p frames that reach them."""
+    M, m = 64, 8
+    p = 2 * m
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+    n = 1 << 26
+    nfr = n // M
+    dx = ya.gen_complex_dev(SEED + 4, n)
+    dy = ya.DeviceArray(n, np.complex64)
+    q = ya.FirPfbCh(M, p, h)
+    q.analyzer_execute_dev(dx, nfr, dy)
+    ya.synchronize()
+    for f in (0, 1, 7, 8, 15, 16, 255, 256, 257, 1023, 1024, 4 * 256 * 1000 + 9, nfr - 257, nfr - 1):
+        lo = max(0, f - (p - 1))
+        xs = dx.to_numpy((f + 1 - lo) * M, offset=lo * M)
+        want = oracle.FirPfbCh(M, p, h).analyzer_execute(xs)[-1]
+        got = dy.to_numpy(M, offset=f * M)
+        assert rel_l2(got, want) <= 2e-6, f
+    # second call continues the stream (history = last p-1 frames of the first block)
+    dx2 = ya.gen_complex_dev(SEED + 4, 64 * M, first=n)
+    dy2 = ya.DeviceArray(64 * M, np.complex64)
+    q.analyzer_execute_dev(dx2, 64, dy2)
+    ya.synchronize()
+    xs = np.concatenate([dx.to_numpy((p - 1) * M, offset=n - (p - 1) * M), dx2.to_numpy(3 * M)])
+    want = oracle.FirPfbCh(M, p, h).analyzer_execute(xs)[-3:]
+    assert rel_l2(dy2.to_numpy(3 * M).reshape(3, M), want) <= 2e-6
+
+
+def test_config_c5_firpfbch2_256ch_full_size(ya, oracle):
+    """BASELINE config C5 (one GPU's part and the whole band): M 256, m 4, 2^26 complex samples = 524 288 steps
+    (runs of 512 steps).  Sampled steps vs the oracle on the 2m + 1 steps that reach them; one sub-band shard of
+    8 equals the matching channels."""
+    M, m = 256, 4
+    M2 = M // 2
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
+    h = (h * M / h.sum()).astype(np.float32)
+    n = 1 << 26
+    ns = n // M2
+    dx = ya.gen_complex_dev(SEED + 5, n)
+    dy = ya.DeviceArray(ns * M, np.complex64)
+    q = ya.FirPfbCh2(M, m, h)
+    q.analyzer_execute_dev(dx, ns, dy)
+    ya.synchronize()
+    reach = 4 * m + 2                                   # history is (2m-1) M + M/2 samples = 4m - 1 steps; even start
+    for s in (0, 1, 2, 15, 16, 17, 511, 512, 513, 512 * 300 + 6, 512 * 300 + 7, ns - 513, ns - 2, ns - 1):
+        lo = max(0, s - reach) & ~1                     # even first step keeps the oracle's step parity
+        xs = dx.to_numpy((s + 1 - lo) * M2, offset=lo * M2)
+        want = oracle.FirPfbCh2(M, m, h).analyzer_execute(xs)[-1]
+        if lo > 0:                                      # zero history differs from the stream's only beyond reach
+            got = dy.to_numpy(M, offset=s * M)
+            assert rel_l2(got, want) <= 3e-6, s
+        else:
+            assert rel_l2(dy.to_numpy(M, offset=s * M), want) <= 3e-6, s
+    R, r = 8, 3
+    shard = ya.DeviceArray(ns * (M // R), np.complex64)
+    qs = ya.FirPfbCh2(M, m, h)
+    qs.analyzer_execute_shard_dev(dx, ns, r, R, shard)
+    ya.synchronize()
+    for s in (0, 513, ns - 1):
+        full = dy.to_numpy(M, offset=s * M)
+        assert rel_l2(shard.to_numpy(M // R, offset=s * (M // R)), full[r::R]) <= 3e-6, s

@@ -120,3 +120,18 @@ def test_config_c3_fft_4096_batch_65536(ya, oracle):
         assert abs(e_in - e_out) <= 1e-5 * e_in
     dx.free()
     dy.free()
+
+
+@pytest.mark.parametrize("n", [16, 128, 256, 512, 1024, 2048, 8192, 100, 1000, 509])
+def test_fft_large_batch_on_device(ya, oracle, n):
+    """many workgroups / several transforms per workgroup / a partial last workgroup (and, for 509, several
+    passes through the Bluestein scratch): 2^21+ points on device buffers, sampled transforms vs the f64 DFT"""
+    batch = (1 << 21) // n + 3
+    dx = ya.gen_complex_dev(SEED + 3, batch * n)
+    dy = ya.DeviceArray(batch * n, np.complex64)
+    plan = ya.Fft(n, ya.Direction.Forward)
+    plan.run_batch_dev(dx, dy, batch)
+    ya.synchronize()
+    for b in (0, 1, 5, batch // 2, batch - 2, batch - 1):
+        truth = oracle.dft_f64(dx.to_numpy(n, offset=b * n))
+        assert rel_l2(dy.to_numpy(n, offset=b * n), truth) <= 1e-5, b
