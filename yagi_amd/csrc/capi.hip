@@ -1381,7 +1381,7 @@ struct SpgramObj {
     float alpha = 1.0f, gamma = 1.0f;
     bool accumulate = true;
     DevWindow<T> buf;
-    DevBuf w, psd, out, tbuf, fbuf;
+    DevBuf w, psd, out, tbuf, fbuf, part;
     FftPlan plan;
     Workspace ws;
     std::vector<T> queue;                // samples push()ed since the last flush
@@ -1455,7 +1455,9 @@ struct SpgramObj {
             YG_TRY(launch_spgram_frames<T>(buf.dev(), x, w.as<float>(), wlen, nfft, first + (long long)f0 * delay, delay,
                                            nf, tbuf.as<cf32>(), st));
             YG_TRY(launch_fft_batch(plan.d, tbuf.as<cf32>(), fbuf.as<cf32>(), nf, st));
-            YG_TRY(launch_spgram_accum(fbuf.as<cf32>(), nfft, nf, alpha, gamma, num_transforms == 0, psd.as<float>(), st));
+            YG_TRY(part.ensure(spgram_accum_scratch_floats(nfft, nf) * sizeof(float)));
+            YG_TRY(launch_spgram_accum(fbuf.as<cf32>(), nfft, nf, alpha, gamma, num_transforms == 0, psd.as<float>(),
+                                       part.as<float>(), st));
             num_transforms += nf;
             num_transforms_total += nf;
         }

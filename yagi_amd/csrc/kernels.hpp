@@ -119,8 +119,10 @@ int launch_fftfilt_ola(const cf32 *t, const cf32 *w, int n, size_t nblocks, C sc
 template <class T>
 int launch_spgram_frames(const T *win, const T *x, const float *w, int wlen, int nfft, long long first,
                          int delay, size_t nframes, cf32 *time, hipStream_t st);
+size_t spgram_accum_scratch_floats(int nfft, size_t nframes);
+// `part`: spgram_accum_scratch_floats(nfft, nframes) floats of scratch
 int launch_spgram_accum(const cf32 *freq, int nfft, size_t nframes, float alpha, float gamma, bool first_ever,
-                        float *psd, hipStream_t st);
+                        float *psd, float *part, hipStream_t st);
 int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float *out, hipStream_t st);
 
 // ---- chan_kernels.hip ----------------------------------------------------------------------
