@@ -1446,7 +1446,21 @@ struct SpgramObj {
         return YAGI_OK;
     }
     // transforms whose newest sample is X[first + f*delay], f < nframes (X = window ++ x)
-    int run_frames(const T *x, long long first, size_t nframes) {
+    // x_len = samples readable at x (the write() block)
+    int run_frames(const T *x, long long first, size_t nframes, size_t x_len = 0) {
+        if (nfft == 4096 && !plan.d.bs_m) {       // fused taper -> FFT -> |X|^2 -> accumulate (spgram_kernels.hip)
+            const size_t big = (size_t)1 << 20;   // transforms per launch
+            for (size_t f0 = 0; f0 < nframes; f0 += big) {
+                const size_t nf = (nframes - f0) < big ? (nframes - f0) : big;
+                YG_TRY(part.ensure(spgram_fused_scratch_floats(nf) * sizeof(float)));
+                YG_TRY(launch_spgram_fused4096<T>(buf.dev(), x, x_len, w.as<float>(), wlen, first + (long long)f0 * delay, delay, nf,
+                                                  alpha, gamma, num_transforms == 0, plan.d.tw, psd.as<float>(),
+                                                  part.as<float>(), st));
+                num_transforms += nf;
+                num_transforms_total += nf;
+            }
+            return YAGI_OK;
+        }
         const size_t chunk = 8192;
         for (size_t f0 = 0; f0 < nframes; f0 += chunk) {
             const size_t nf = (nframes - f0) < chunk ? (nframes - f0) : chunk;
@@ -1468,7 +1482,7 @@ struct SpgramObj {
         const size_t t = sample_timer;                               // 1..delay pushes until the next transform
         size_t nframes = 0;
         if (n >= t) nframes = (n - t) / (size_t)delay + 1;
-        if (nframes) YG_TRY(run_frames(x, (long long)t - 1, nframes));
+        if (nframes) YG_TRY(run_frames(x, (long long)t - 1, nframes, n));
         sample_timer = (n < t) ? t - n : (size_t)delay - (n - t) % (size_t)delay;
         num_samples += n;
         num_samples_total += n;

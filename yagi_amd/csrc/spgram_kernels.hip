@@ -8,7 +8,7 @@
 // per bin is the reference's).
 #include <cmath>
 
-#include "devmath.hpp"
+#include "fft_core.hpp"
 #include "kernels.hpp"
 
 namespace yagi {
@@ -84,6 +84,90 @@ spgram_psd_kernel(const float *__restrict__ psd, int nfft, float scale, int in_d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused form for nfft = 4096 (spgram.rs:263-284 in one kernel): a workgroup walks `slab` consecutive
+// transforms; each is tapered while it is loaded (lane t holds window taps 256a + t in registers), transformed
+// in registers (fft4096_passes_to_regs) and its |X|^2 added into 16 per-lane accumulators with the weight the
+// recurrence p = gamma p + alpha |X|^2 gives frame f of the batch: alpha gamma^(nframes-1-f) (the first frame
+// ever: gamma^(nframes-1)).  Neither the tapered frames nor the spectra touch HBM: the input is read once
+// (overlapping frames hit in L2) and one float per bin and slab is written.  spgram_sum_kernel then adds the
+// slab partials in a fixed order and applies gamma^nframes to the previous estimate.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+spgram_fused4096_kernel(const T *__restrict__ win, const T *__restrict__ x, const float *__restrict__ w, int wlen,
+                        long long first, long long x_len, int delay, unsigned nframes, unsigned slab, float alpha,
+                        float log2_gamma, int first_ever, const float2 *__restrict__ tw, float *__restrict__ part) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x;
+    float wt[16];
+#pragma unroll
+    for (unsigned a = 0; a < 16; ++a) wt[a] = (int)(256u * a + t) < wlen ? w[256u * a + t] : 0.0f;
+    float acc[16];
+#pragma unroll
+    for (unsigned d = 0; d < 16; ++d) acc[d] = 0.0f;
+    const unsigned f0 = blockIdx.x * slab;
+    const unsigned f1 = (f0 + slab < nframes) ? f0 + slab : nframes;
+#pragma unroll 1
+    for (unsigned f = f0; f < f1; ++f) {
+        // offset the optimiser cannot see through: otherwise the twiddle loads AND their products are hoisted
+        // out of the frame loop and sit in ~60 VGPRs
+        unsigned z = 0;
+        asm volatile("" : "+s"(z));
+        const long long base = first + (long long)f * delay - (wlen - 1);       // stream index of frame sample 0
+        float2 v[16];
+        if (base >= 0 && base + 4096 <= x_len) {           // block-uniform: all 4096 slots of the frame lie in x
+            const T *src = x + base;                       // uniform base + 32-bit lane offset, unconditional loads
+#pragma unroll
+            for (unsigned a = 0; a < 16; ++a) {
+                const unsigned k = 256u * a + t;
+                const float2 sv = sp_cx(src[k], wt[a]);
+                v[a] = (int)k < wlen ? sv : make_float2(0.f, 0.f);     // a select, not a branch
+            }
+        } else {                                           // reaches into the window: rolled loop through LDS
+#pragma unroll 1
+            for (int k = (int)t; k < 4096; k += 256) {
+                float2 sv = make_float2(0.f, 0.f);
+                if (k < wlen) {
+                    const long long idx = base + k;
+                    sv = sp_cx((idx < 0) ? win[wlen + idx] : x[idx], w[k]);
+                }
+                lds[k] = sv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned a = 0; a < 16; ++a) v[a] = lds[256u * a + t];
+            __syncthreads();
+        }
+        fft4096_passes_to_regs<-1>(v, lds, tw + z);
+        float wgt = exp2f(log2_gamma * (float)(nframes - 1 - f));
+        if (!(first_ever && f == 0)) wgt *= alpha;
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) acc[d] = fmaf(wgt, v[d].x * v[d].x + v[d].y * v[d].y, acc[d]);
+    }
+    float *dst = part + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (unsigned d = 0; d < 16; ++d) dst[t + 256u * d] = acc[d];
+}
+
+// psd[i] <- (first_ever ? 0 : gpow psd[i]) + sum_s part[s][i]; 4 partial sums per bin, combined in a fixed order
+__global__ void __launch_bounds__(256)
+spgram_sum_kernel(const float *__restrict__ part, int nfft, unsigned nslabs, float gpow, int first_ever,
+                  float *__restrict__ psd) {
+    __shared__ float red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned ty = threadIdx.x >> 6;
+    float q = 0.0f;
+    if (i < nfft)
+        for (unsigned s = ty; s < nslabs; s += 4) q += part[(size_t)s * nfft + i];
+    red[ty][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (ty == 0 && i < nfft) {
+        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        psd[i] = first_ever ? sum : gpow * psd[i] + sum;
+    }
+}
+
 static unsigned sp_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -117,6 +201,35 @@ int launch_spgram_accum(const cf32 *freq, int nfft, size_t nframes, float alpha,
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
+// fused nfft = 4096 path; part: spgram_fused_scratch_floats(nframes) floats
+static unsigned spgram_fused_slab(size_t nframes) {
+    size_t sl = nframes / 1024;
+    return (unsigned)(sl < 4 ? 4 : (sl > 32 ? 32 : sl));
+}
+size_t spgram_fused_scratch_floats(size_t nframes) {
+    const unsigned slab = spgram_fused_slab(nframes);
+    return ((nframes + slab - 1) / slab) * (size_t)4096;
+}
+template <class T>
+int launch_spgram_fused4096(const T *win, const T *x, size_t x_len, const float *w, int wlen, long long first,
+                            int delay, size_t nframes, float alpha, float gamma, bool first_ever, const cf32 *tw4096,
+                            float *psd, float *part, hipStream_t st) {
+    if (nframes == 0) return YAGI_OK;
+    if (nframes > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "too many transforms in one call");
+    const unsigned slab = spgram_fused_slab(nframes);
+    const unsigned nslabs = (unsigned)((nframes + slab - 1) / slab);
+    const float l2g = (float)std::log2((double)gamma);
+    spgram_fused4096_kernel<T><<<nslabs, 256, 0, st>>>(win, x, w, wlen, first, (long long)x_len, delay, (unsigned)nframes, slab, alpha, l2g,
+                                                      first_ever ? 1 : 0, reinterpret_cast<const float2 *>(tw4096), part);
+    YG_LAUNCH_CHECK();
+    spgram_sum_kernel<<<4096 / 64, 256, 0, st>>>(part, 4096, nslabs, (float)std::pow((double)gamma, (double)nframes),
+                                                first_ever ? 1 : 0, psd);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+template int launch_spgram_fused4096<float>(const float *, const float *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
+template int launch_spgram_fused4096<cf32>(const cf32 *, const cf32 *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
+
 int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float *out, hipStream_t st) {
     spgram_psd_kernel<<<sp_grid((size_t)nfft), 256, 0, st>>>(psd, nfft, scale, in_db ? 1 : 0, out);
     YG_LAUNCH_CHECK();
