@@ -36,8 +36,8 @@ def test_fftfilt_golden(ya, oracle, kind, case):
     per_call = np.concatenate([q.execute(x[i:i + n]) for i in range(0, len(x), n)])
     np.testing.assert_allclose(per_call[:len(y)], y, atol=1e-3, rtol=0)
     q.reset()
-    batched = q.execute_blocks(x)                      # same blocks as one device batch
-    assert np.array_equal(batched, per_call)
+    batched = q.execute_blocks(x)                      # same samples as one device batch (FFT blocks fall differently)
+    np.testing.assert_allclose(batched, per_call, atol=2e-6 * max(1.0, float(np.max(np.abs(per_call)))), rtol=0)
     ref = oracle.FftFilt(kind, h, n)
     want = np.concatenate([ref.execute(x[i:i + n]) for i in range(0, len(x), n)])
     np.testing.assert_allclose(per_call, want, atol=2e-6)
@@ -76,7 +76,8 @@ def test_fftfilt_copy(ya, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("L,n", [(1, 1), (5, 4), (64, 64), (256, 2048), (257, 256), (1000, 4096), (100, 100)])
+@pytest.mark.parametrize("L,n", [(1, 1), (5, 4), (64, 64), (256, 2048), (257, 256), (1000, 4096), (100, 100), (2049, 2048),
+                                 (2050, 2049), (3000, 4096)])      # > 2049 taps: the five-stage overlap-add path
 def test_fftfilt_equals_direct_form(ya, oracle, kind, L, n):
     """fast convolution == firfilt (f64 truth) for ragged block counts and carried state"""
     rng = np.random.default_rng(L + n)

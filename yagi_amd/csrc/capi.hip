@@ -1662,6 +1662,12 @@ struct FftFiltObj {
     int cur = 0;
     DevBuf tbuf, fbuf;              // [nblocks][2n] time / frequency buffers
     Workspace ws;
+    // h_len <= 2049: the blocks of one call are contiguous in the stream and what FftFilt computes is the
+    // stream's linear convolution with h, whatever the block length -- so the call goes to the one-launch
+    // overlap-save kernel (4096-point transforms chained in registers) and the carried state is the last h_len
+    // input samples instead of the overlap-add tail.  Longer filters keep the reference's five stages.
+    bool use_conv = false;
+    FirFilt<K> fir;
 
     int init(const C *hh, size_t h_len, size_t nn) {
         if (h_len == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
@@ -1671,6 +1677,14 @@ struct FftFiltObj {
         YG_TRY(require_device());
         h.assign(hh, hh + h_len);
         n = (int)nn;
+        scale = div_scalar(one_of<C>(), 2.0f * (float)n);
+        use_conv = h_len <= 2049;
+        if (use_conv) {
+            fir.st = st;
+            YG_TRY(fir.init(hh, h_len));
+            fir.kernel_choice = 4;
+            return YAGI_OK;
+        }
         YG_TRY(fft_plan_init(fwd, 2 * nn, YAGI_FFT_FORWARD));
         YG_TRY(fft_plan_init(bwd, 2 * nn, YAGI_FFT_BACKWARD));
         std::vector<cf32> tb(2 * nn, cf32{0.f, 0.f});
@@ -1685,11 +1699,17 @@ struct FftFiltObj {
         return reset();
     }
     int reset() {
+        if (use_conv) return fir.w.reset(st);
         YG_HIP(hipMemsetAsync(w[cur].p, 0, (size_t)n * sizeof(cf32), st));
         return YAGI_OK;
     }
     int blocks_dev(const T *x, size_t nblocks, T *y) {
         if (nblocks == 0) return YAGI_OK;
+        if (use_conv) {
+            fir.st = st;
+            fir.scale = mul_scalar(scale, 2.0f * (float)n);         // the caller's scale (ours is stored / 2n)
+            return fir.block_dev(x, nblocks * (size_t)n, y);
+        }
         const size_t n2 = 2 * (size_t)n;
         YG_TRY(tbuf.ensure(nblocks * n2 * sizeof(cf32)));
         YG_TRY(fbuf.ensure(nblocks * n2 * sizeof(cf32)));
@@ -1739,9 +1759,14 @@ struct FftFiltObj {
         o->st = q->st;                                                                              \
         YG_TRY(o->init(q->h.data(), q->h.size(), (size_t)q->n));                                    \
         o->scale = q->scale;                                                                        \
-        YG_HIP(hipMemcpyAsync(o->w[o->cur].p, q->w[q->cur].p, (size_t)q->n * sizeof(cf32),          \
-                              hipMemcpyDeviceToDevice, q->st));                                     \
-        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        if (q->use_conv) {                                                                          \
+            YG_TRY(q->fir.w.flush(q->st));                                                          \
+            YG_TRY(o->fir.w.clone_from(q->fir.w, q->st));                                           \
+        } else {                                                                                    \
+            YG_HIP(hipMemcpyAsync(o->w[o->cur].p, q->w[q->cur].p, (size_t)q->n * sizeof(cf32),      \
+                                  hipMemcpyDeviceToDevice, q->st));                                 \
+            YG_HIP(hipStreamSynchronize(q->st));                                                    \
+        }                                                                                           \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
     }                                                                                               \
