@@ -89,9 +89,10 @@ def test_firpfbch2_vs_oracle(ya, oracle, M, m):
     assert rel_l2(q.analyzer_execute(x[: 9 * M2]), want[:9]) <= 2e-6
 
 
-@pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200)])
+@pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200), (64, 8, 700),
+                                    (128, 8, 130)])
 def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
-    """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8}, even first step) incl. ragged tails"""
+    """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8,16}, even first step) incl. ragged tails"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
     h = (h * M / h.sum()).astype(np.float32)
     M2 = M // 2

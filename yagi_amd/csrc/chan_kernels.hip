@@ -583,6 +583,7 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
             YG_COL2_CASE(2)
             YG_COL2_CASE(4)
             YG_COL2_CASE(8)
+            YG_COL2_CASE(16)
             default: break;
         }
 #undef YG_COL2_CASE
