@@ -42,37 +42,54 @@ static FacList factorize_small(int n) {
 
 // nfr independent N-point DFTs stored [frame][N] in LDS buffer `src`; result buffer returned.
 // tw = W_Mtab^m table (forward sign), N * tw_scale == Mtab; conj => inverse transform.
-__device__ __forceinline__ float2 *lds_dft_frames(float2 *src, float2 *dst, int N, int nfr,
-                                                  const FacList &fl, const float2 *__restrict__ tw,
-                                                  int tw_scale, bool conj) {
+// Radices 2/3/4/5/7 run as register butterflies (fft_radix.hpp), any other prime factor as direct sums.
+template <bool CONJ>
+__device__ __forceinline__ float2 *lds_dft_frames_t(float2 *src, float2 *dst, int N, int nfr,
+                                                    const FacList &fl, const float2 *__restrict__ tw,
+                                                    int tw_scale) {
+    constexpr int SIGN = CONJ ? +1 : -1;
     int Ns = 1;
     const int total = N * nfr;
     for (int f = 0; f < fl.n; ++f) {
         const int R = fl.f[f];
         const int T = N / R;
         const int tw_k = N / (Ns * R);
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            const int fr = e / N, idx = e - fr * N;
-            const int q = idx / T, j = idx - q * T;
-            const int k = j % Ns;
-            const int step = (k * tw_k + q * T) % N;
-            const float2 *s = src + fr * N;
-            float2 acc = s[j];
-            int m = 0;
-            for (int r = 1; r < R; ++r) {
-                m += step;
-                if (m >= N) m -= N;
-                float2 w = tw[m * tw_scale];
-                if (conj) w.y = -w.y;
-                acc = cadd(acc, cmul(s[j + r * T], w));
-            }
-            dst[fr * N + (j / Ns) * Ns * R + k + q * Ns] = acc;
+        switch (R) {
+            case 2: stockham_pass_any<2, SIGN>(src, dst, N, Ns, nfr, tw, tw_scale, CONJ); break;
+            case 3: stockham_pass_any<3, SIGN>(src, dst, N, Ns, nfr, tw, tw_scale, CONJ); break;
+            case 4: stockham_pass_any<4, SIGN>(src, dst, N, Ns, nfr, tw, tw_scale, CONJ); break;
+            case 5: stockham_pass_any<5, SIGN>(src, dst, N, Ns, nfr, tw, tw_scale, CONJ); break;
+            case 7: stockham_pass_any<7, SIGN>(src, dst, N, Ns, nfr, tw, tw_scale, CONJ); break;
+            default:
+                for (int e = threadIdx.x; e < total; e += blockDim.x) {
+                    const int fr = e / N, idx = e - fr * N;
+                    const int q = idx / T, j = idx - q * T;
+                    const int k = j % Ns;
+                    const int step = (k * tw_k + q * T) % N;
+                    const float2 *s = src + fr * N;
+                    float2 acc = s[j];
+                    int m = 0;
+                    for (int r = 1; r < R; ++r) {
+                        m += step;
+                        if (m >= N) m -= N;
+                        float2 w = tw[m * tw_scale];
+                        if (CONJ) w.y = -w.y;
+                        acc = cadd(acc, cmul(s[j + r * T], w));
+                    }
+                    dst[fr * N + (j / Ns) * Ns * R + k + q * Ns] = acc;
+                }
         }
         __syncthreads();
         float2 *t = src; src = dst; dst = t;
         Ns *= R;
     }
     return src;
+}
+__device__ __forceinline__ float2 *lds_dft_frames(float2 *src, float2 *dst, int N, int nfr,
+                                                  const FacList &fl, const float2 *__restrict__ tw,
+                                                  int tw_scale, bool conj) {
+    return conj ? lds_dft_frames_t<true>(src, dst, N, nfr, fl, tw, tw_scale)
+                : lds_dft_frames_t<false>(src, dst, N, nfr, fl, tw, tw_scale);
 }
 
 __device__ __forceinline__ float2 load_hist(const float2 *__restrict__ hist, int hist_len,
@@ -299,7 +316,9 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
     if (F < 1) F = 1;
     const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
     auto need = [&](int f) { return ((size_t)(f + p - 1) * M + 2 * (size_t)f * M) * sizeof(float2) + fixed; };
-    while (F > 1 && need(F) > kChanLdsBudget) F /= 2;
+    // wide banks: a tile of one frame re-reads every sample p times; let such shapes use half the LDS (2 WGs per CU)
+    const size_t budget = M >= 512 ? 78 * 1024 : kChanLdsBudget;
+    while (F > 1 && need(F) > budget) F /= 2;
     if (need(F) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch: M*p too large for LDS (%d x %d)", M, p);
     const bool pow2 = is_pow2(M);
     const void *fn = pow2 ? reinterpret_cast<const void *>(firpfbch_kernel<true>)
@@ -592,7 +611,8 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     if (S < 1) S = 1;
     const size_t fixed = (size_t)M * sizeof(float2) + (size_t)p * M * sizeof(float);
     auto need = [&](int s) { return 2 * (size_t)s * M * sizeof(float2) + fixed; };
-    while (S > 1 && need(S) > kChanLdsBudget) S /= 2;
+    const size_t budget = M >= 512 ? 78 * 1024 : kChanLdsBudget;
+    while (S > 1 && need(S) > budget) S /= 2;
     if (need(S) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch2: M*m too large for LDS (%d x %d)", M, m);
     const int Mr = M / nranks;
     const bool pow2 = is_pow2(Mr);

@@ -174,12 +174,14 @@ __device__ __forceinline__ float2 *lds_fft_pow2(float2 *src, float2 *dst, int N,
 
 // Mixed-radix form of stockham_pass: N, Ns, T = N/R arbitrary (index math by division), table twiddles
 // W_N^m with the direction's sign already applied.  R in {2,3,4,5,7,8,16}: register butterfly.
+// tw_scale / conj_tw: the table is W_{N tw_scale}^m with forward sign and SIGN > 0 wants its conjugate (channelizers)
 template <int R, int SIGN>
 __device__ __forceinline__ void stockham_pass_any(const float2 *__restrict__ src, float2 *__restrict__ dst,
-                                                  int N, int Ns, int nfr, const float2 *__restrict__ twl) {
+                                                  int N, int Ns, int nfr, const float2 *__restrict__ twl,
+                                                  int tw_scale = 1, bool conj_tw = false) {
     const int T = N / R;
     const int total = T * nfr;
-    const int tw_k = N / (Ns * R);
+    const int tw_k = (N / (Ns * R)) * tw_scale;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int fr = e / T, j = e - fr * T;
         const int k = j % Ns;
@@ -189,7 +191,11 @@ __device__ __forceinline__ void stockham_pass_any(const float2 *__restrict__ src
         for (int r = 0; r < R; ++r) v[r] = s[r * T];
         if (Ns > 1) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], twl[k * r * tw_k]);
+            for (int r = 1; r < R; ++r) {
+                float2 w = twl[k * r * tw_k];
+                if (conj_tw) w.y = -w.y;
+                v[r] = cmul(v[r], w);
+            }
         }
         dftR<R, SIGN>(v);
         float2 *d = dst + fr * N + (j - k) * R + k;
