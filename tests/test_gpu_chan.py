@@ -32,9 +32,11 @@ def test_firpfbch_vs_oracle(ya, oracle, M, m):
     assert rel_l2(q.analyzer_execute(x[: 5 * M]), want[:5]) <= 2e-6
 
 
-@pytest.mark.parametrize("M,m,nfr", [(64, 8, 4099), (64, 2, 1000), (128, 4, 777), (256, 8, 300), (256, 2, 64), (64, 4, 65)])
+@pytest.mark.parametrize("M,m,nfr", [(64, 8, 4099), (64, 2, 1000), (128, 4, 777), (256, 8, 300), (256, 2, 64), (64, 4, 65),
+                                     (512, 4, 333), (512, 2, 64), (1024, 2, 200), (1024, 4, 77), (512, 4, 20000)])
 def test_firpfbch_column_kernel_long_runs(ya, oracle, M, m, nfr):
-    """the column-sliding kernel (M in {64,128,256}, p in {4,8,16}): ragged frame counts, carried state"""
+    """the column-sliding kernels (M in {64,128,256}, p in {4,8,16}; wide banks M in {512,1024}, p in {4,8}): ragged
+    frame counts, carried state; 20000 frames of 512 channels run several tiles per workgroup"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
     x = oracle.gen_complex(SEED + 4, nfr * M)
     want = oracle.FirPfbCh(M, 2 * m, h).analyzer_execute(x)

@@ -290,6 +290,120 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     return YAGI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// firpfbch, column-sliding form for wide banks (M = 512, 1024; p in {4, 8}): one workgroup per run of frames, every
+// lane owns M/256 branch columns (taps and ring per column in registers), half tiles of HF = 4096/M frames so
+// the two transform buffers stay at 32 KiB each; three static radix passes (512 = 8x8x8, 1024 = 16x8x8).
+// The generic tiled kernel re-reads every sample (tile + p - 1)/tile times and got 0.4-0.8 TB/s on these shapes.
+// ---------------------------------------------------------------------------------------------
+template <int P, int LGM>
+__global__ void __launch_bounds__(256)
+firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                     const float *__restrict__ h, const float2 *__restrict__ twM,
+                     float2 *__restrict__ y, size_t nframes, int run) {
+    constexpr int M = 1 << LGM, lgM = LGM, C = M / 256, HF = 4096 / M, TILE = 2 * HF;
+    constexpr int R0 = LGM == 9 ? 8 : 16;                        // then 8 x 8
+    constexpr int nq = HF, lgnq = LGM == 9 ? 3 : 2;
+    constexpr int pitch = M + 32 / nq;
+    static_assert(TILE % P == 0, "ring slots must be static");
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *va = reinterpret_cast<float2 *>(smem);               // [HF frames][pitch]
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;                               // M
+    const int t = threadIdx.x;
+    for (int e = t; e < M; e += 256) twl[e] = twM[e];
+    float hc[C][P];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc)
+#pragma unroll
+        for (int n = 0; n < P; ++n) hc[cc][n] = h[(M - 1 - (t + 256 * cc)) + n * M];
+    const int hist_len = (P - 1) * M;
+    const long long x_len = (long long)nframes * M;
+    const long long f_begin = (long long)blockIdx.x * run;
+    const long long left = (long long)nframes - f_begin;
+    const int nvalid = (int)(left < run ? left : run);
+    const bool full = nvalid == run;
+    const float2 *xg = x + f_begin * M + t;
+    float2 w[C][P];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc)
+#pragma unroll
+        for (int n = 1; n < P; ++n)
+            w[cc][P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + t + 256 * cc, x_len);
+    float2 xa[C][HF], xb[C][HF];
+    auto loadh = [&](float2 (&d)[C][HF], int f) {
+#pragma unroll
+        for (int j = 0; j < HF; ++j)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc)
+                d[cc][j] = (full || f + j < nvalid) ? xg[((unsigned)(f + j) << lgM) + 256u * cc] : make_float2(0.f, 0.f);
+    };
+    float2 *yb = y + f_begin * M;
+    auto half_tile = [&](float2 (&xin)[C][HF], int f, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
+#pragma unroll
+        for (int j = 0; j < HF; ++j)
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+                w[cc][(S0 + j) % P] = xin[cc][j];
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < P; ++n) {
+                    const float2 sv = w[cc][(S0 + j - n + 4 * P) % P];
+                    acc.x = fmaf(sv.x, hc[cc][n], acc.x);
+                    acc.y = fmaf(sv.y, hc[cc][n], acc.y);
+                }
+                va[j * pitch + t + 256 * cc] = acc;
+            }
+        if (f + TILE < run) loadh(xin, f + TILE);
+        __syncthreads();
+        stockham_pass<R0, -1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        stockham_pass<8, -1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        stockham_pass<8, -1, true>(va, vb, M, R0 * 8, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HF * C; ++i) {
+            const int e = t + 256 * i;
+            const int q = e >> lgM, k = e & (M - 1);
+            if (full || f + q < nvalid) yb[((unsigned)(f + q) << lgM) + k] = vb[q * pitch + k];
+        }
+        __syncthreads();
+    };
+    loadh(xa, 0);
+    loadh(xb, HF);
+    for (int f0 = 0; f0 < run; f0 += TILE) {
+        half_tile(xa, f0, std::integral_constant<int, 0>{});
+        half_tile(xb, f0 + HF, std::integral_constant<int, HF>{});
+    }
+}
+
+template <int P, int LGM>
+static int launch_firpfbch_wide(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
+                                cf32 *y, size_t nframes, hipStream_t st) {
+    constexpr int M = 1 << LGM, HF = 4096 / M, TILE = 2 * HF;
+    size_t run = nframes / (size_t)YG_COL_WGS;
+    run = run / TILE * TILE;
+    if (run < (size_t)TILE) run = TILE;
+    if (run > 256) run = 256;
+    const size_t nblk = (nframes + run - 1) / run;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const size_t lds = (2 * (size_t)HF * (M + 32 / HF) + (size_t)M) * sizeof(float2);
+    static bool raised = false;
+    if (!raised) {
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_wide_kernel<P, LGM>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    firpfbch_wide_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
+                                                                  reinterpret_cast<const float2 *>(x), h,
+                                                                  reinterpret_cast<const float2 *>(twM),
+                                                                  reinterpret_cast<float2 *>(y), nframes, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 static constexpr size_t kChanLdsBudget = 38 * 1024;   // <= 4 workgroups per CU
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -297,6 +411,12 @@ static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
                     const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
+    if ((M == 512 || M == 1024) && (p == 4 || p == 8) && nframes >= 64) {
+        if (M == 512) return p == 4 ? launch_firpfbch_wide<4, 9>(hist, x, h, twM, y, nframes, st)
+                                    : launch_firpfbch_wide<8, 9>(hist, x, h, twM, y, nframes, st);
+        return p == 4 ? launch_firpfbch_wide<4, 10>(hist, x, h, twM, y, nframes, st)
+                      : launch_firpfbch_wide<8, 10>(hist, x, h, twM, y, nframes, st);
+    }
     if ((M == 64 || M == 128 || M == 256) && nframes >= 64) {
 #define YG_COL_CASE(PP)                                                                              \
     case PP:                                                                                         \
