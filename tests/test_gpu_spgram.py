@@ -143,19 +143,24 @@ def test_spgram_device_stream_4096(ya, oracle):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.float32])
-@pytest.mark.parametrize("wlen,delay,alpha", [(4096, 2048, -1.0), (3000, 777, -1.0), (4096, 4096, 0.2), (1234, 100, 0.05)])
-def test_spgram_fused_4096_vs_oracle(ya, oracle, dtype, wlen, delay, alpha):
-    """nfft = 4096 takes the fused taper -> FFT -> |X|^2 -> accumulate kernel: bin-level parity with the oracle's
-    step-by-step restatement for both sample types, window shorter than nfft, odd delay, split writes (window
-    carried across calls: the first frames of a call reach into it), and the recursive-average mode"""
-    n = 40 * 4096 + 321
+@pytest.mark.parametrize("nfft", [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("shape", [(1.0, 0.5, -1.0), (0.73, 0.19, -1.0), (1.0, 1.0, 0.2), (0.3, 0.025, 0.05)])
+def test_spgram_fused_vs_oracle(ya, oracle, dtype, nfft, shape):
+    """nfft in {256..4096} takes the fused taper -> FFT -> |X|^2 -> accumulate kernels: bin-level parity with the
+    oracle's step-by-step restatement for both sample types, window shorter than nfft, odd delay, split writes
+    (window carried across calls: the first frames of a call reach into it), and the recursive-average mode"""
+    wlen = max(2, int(shape[0] * nfft))
+    wlen += wlen % 2 == 1 and wlen < nfft            # even (Hann does not need it; keeps the shapes tidy)
+    delay = max(1, int(shape[1] * nfft) | 1) if shape[1] < 0.5 else int(shape[1] * nfft)
+    alpha = shape[2]
+    n = 12 * 4096 + 321 if nfft < 4096 else 40 * 4096 + 321
     x = (oracle.gen_real(21, n) if dtype == np.float32 else noise(oracle, n)) * np.float32(3e-2)
-    ref = oracle.Spgram(4096, 2, wlen, delay, dtype=dtype)
-    q = ya.Spgram(4096, ya.WindowType.Hann, wlen, delay, dtype=dtype)
+    ref = oracle.Spgram(nfft, 2, wlen, delay, dtype=dtype)
+    q = ya.Spgram(nfft, ya.WindowType.Hann, wlen, delay, dtype=dtype)
     if alpha >= 0:
         ref.set_alpha(alpha)
         q.set_alpha(alpha)
-    for lo, hi in [(0, 5000), (5000, 5003), (5003, 90000), (90000, n)]:
+    for lo, hi in [(0, 5000), (5000, 5003), (5003, n // 2 + 7), (n // 2 + 7, n)]:
         ref.write(x[lo:hi])
         q.write(x[lo:hi])
         assert q.get_num_transforms() == ref.num_transforms

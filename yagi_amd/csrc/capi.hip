@@ -1448,12 +1448,12 @@ struct SpgramObj {
     // transforms whose newest sample is X[first + f*delay], f < nframes (X = window ++ x)
     // x_len = samples readable at x (the write() block)
     int run_frames(const T *x, long long first, size_t nframes, size_t x_len = 0) {
-        if (nfft == 4096 && !plan.d.bs_m) {       // fused taper -> FFT -> |X|^2 -> accumulate (spgram_kernels.hip)
+        if (spgram_fused_supported(nfft)) {       // fused taper -> FFT -> |X|^2 -> accumulate (spgram_kernels.hip)
             const size_t big = (size_t)1 << 20;   // transforms per launch
             for (size_t f0 = 0; f0 < nframes; f0 += big) {
                 const size_t nf = (nframes - f0) < big ? (nframes - f0) : big;
-                YG_TRY(part.ensure(spgram_fused_scratch_floats(nf) * sizeof(float)));
-                YG_TRY(launch_spgram_fused4096<T>(buf.dev(), x, x_len, w.as<float>(), wlen, first + (long long)f0 * delay, delay, nf,
+                YG_TRY(part.ensure(spgram_fused_scratch_floats(nfft, nf) * sizeof(float)));
+                YG_TRY(launch_spgram_fused<T>(nfft, buf.dev(), x, x_len, w.as<float>(), wlen, first + (long long)f0 * delay, delay, nf,
                                                   alpha, gamma, num_transforms == 0, plan.d.tw, psd.as<float>(),
                                                   part.as<float>(), st));
                 num_transforms += nf;

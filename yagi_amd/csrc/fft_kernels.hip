@@ -48,9 +48,6 @@ __global__ void __launch_bounds__(256)
 fft_n256m_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
                  size_t batch) {
     constexpr int N = 256 * M, LT = 16 * M, B = 16 / M;          // points, lanes per transform, transforms per WG
-    constexpr int S1 = 17 * M, T1 = 16 * S1;                    // exchange 1: row stride, transform stride
-    constexpr int S2 = 256 + 16 / M, T2 = M * S2;               // exchange 2
-    static_assert(B * T1 <= kFft4096LdsFloat2 && B * T2 <= kFft4096LdsFloat2, "LDS layout");
     __shared__ float2 lds[kFft4096LdsFloat2];
     const unsigned t = threadIdx.x, tr = t / LT, u = t % LT;
     const size_t g = (size_t)blockIdx.x * B + tr;
@@ -59,54 +56,13 @@ fft_n256m_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const 
     float2 v[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a] = live ? src[LT * a + u] : make_float2(0.f, 0.f);
-    // ---- pass 1 ----
-    dft16<SIGN>(v);
-    {
-        float2 w[16];
-        twiddle_powers(w, tw, u, (unsigned)(N - 1));             // W_N^{u c}: u c < N, the mask never wraps
-        float2 *e1 = lds + tr * T1 + u;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float2 z = v[dft16_pos(c)];
-            if (c) z = cmul(z, w[c]);
-            e1[c * S1] = z;
-        }
-    }
-    __syncthreads();
-    // ---- pass 2 ----
-    {
-        const unsigned c = u / M, bp = u % M;
-        const float2 *e1 = lds + tr * T1 + c * S1 + bp;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = e1[M * a];
-        __syncthreads();                                         // exchange-1 reads done before the buffer is reused
-        dft16<SIGN>(v);
-        float2 w[16];
-        twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));      // W_{16M}^{b' c'} = W_N^{16 b' c'}
-        float2 *e2 = lds + tr * T2 + bp * S2 + c;
-#pragma unroll
-        for (int cp = 0; cp < 16; ++cp) {
-            float2 z = v[dft16_pos(cp)];
-            if (cp) z = cmul(z, w[cp]);
-            e2[16 * cp] = z;
-        }
-    }
-    __syncthreads();
-    // ---- pass 3: 16/M radix-M butterflies per lane ----
-    {
-        const float2 *e2 = lds + tr * T2 + u;
+    fft_n256m_passes_to_regs<SIGN, M>(v, lds, tw);
+    if (live) {
         float2 *dst = out + g * N + u;
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
-            float2 r[M];
+        for (int i = 0; i < B; ++i)
 #pragma unroll
-            for (int bp = 0; bp < M; ++bp) r[bp] = e2[bp * S2 + LT * i];
-            if constexpr (M > 1) dftR<M, SIGN>(r);
-            if (live) {
-#pragma unroll
-                for (int d = 0; d < M; ++d) dst[LT * i + 256 * d] = r[d];
-            }
-        }
+            for (int d = 0; d < M; ++d) dst[LT * i + 256 * d] = v[i * M + d];
     }
 }
 

@@ -233,4 +233,67 @@ __device__ __forceinline__ void stockham_pass_direct(const float2 *__restrict__ 
 // LDS pitch (float2) of one transform slot when nfr = 2^k <= 32 transforms of <= N points share a pass (FRFAST)
 __host__ __device__ inline int frfast_pitch(int N, int nfr) { return N + 32 / nfr; }
 
+// ---------------------------------------------------------------------------------------------
+// N = 256 M (M in {1, 2, 4, 8}) in registers: the 4096-point scheme with a radix-M last pass.  A 256-lane
+// workgroup owns 16/M transforms; transform tr = t / 16M, lane u = t % 16M within it.
+//   in : v[a] = x[16M a + u], a < 16
+//   out: v[i M + d] = X[u + 16M i + 256 d],  i < 16/M, d < M
+// `lds` = kFft4096LdsFloat2 float2; 3 __syncthreads(), every lane must call it (the caller adds one before
+// reusing `lds`).  Exchange strides 17M and 256 + 16/M keep all LDS accesses bank-conflict free.
+template <int SIGN, int M>
+__device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
+                                                         const float2 *__restrict__ tw) {
+    constexpr int N = 256 * M, LT = 16 * M, B = 16 / M;
+    constexpr int S1 = 17 * M, T1 = 16 * S1;                    // exchange 1: row stride, transform stride
+    constexpr int S2 = 256 + 16 / M, T2 = M * S2;               // exchange 2
+    static_assert(B * T1 <= kFft4096LdsFloat2 && B * T2 <= kFft4096LdsFloat2, "LDS layout");
+    const unsigned t = threadIdx.x, tr = t / LT, u = t % LT;
+    // ---- pass 1 ----
+    dft16<SIGN>(v);
+    {
+        float2 w[16];
+        twiddle_powers(w, tw, u, (unsigned)(N - 1));             // W_N^{u c}: u c < N, the mask never wraps
+        float2 *e1 = lds + tr * T1 + u;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul(z, w[c]);
+            e1[c * S1] = z;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2 ----
+    {
+        const unsigned c = u / M, bp = u % M;
+        const float2 *e1 = lds + tr * T1 + c * S1 + bp;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = e1[M * a];
+        __syncthreads();                                         // exchange-1 reads done before the buffer is reused
+        dft16<SIGN>(v);
+        float2 w[16];
+        twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));      // W_{16M}^{b' c'} = W_N^{16 b' c'}
+        float2 *e2 = lds + tr * T2 + bp * S2 + c;
+#pragma unroll
+        for (int cp = 0; cp < 16; ++cp) {
+            float2 z = v[dft16_pos(cp)];
+            if (cp) z = cmul(z, w[cp]);
+            e2[16 * cp] = z;
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: 16/M radix-M butterflies per lane ----
+    {
+        const float2 *e2 = lds + tr * T2 + u;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            float2 r[M];
+#pragma unroll
+            for (int bp = 0; bp < M; ++bp) r[bp] = e2[bp * S2 + LT * i];
+            if constexpr (M > 1) dftR<M, SIGN>(r);
+#pragma unroll
+            for (int d = 0; d < M; ++d) v[i * M + d] = r[dftR_pos<M>(d)];
+        }
+    }
+}
+
 }  // namespace yagi

@@ -123,12 +123,14 @@ size_t spgram_accum_scratch_floats(int nfft, size_t nframes);
 // `part`: spgram_accum_scratch_floats(nfft, nframes) floats of scratch
 int launch_spgram_accum(const cf32 *freq, int nfft, size_t nframes, float alpha, float gamma, bool first_ever,
                         float *psd, float *part, hipStream_t st);
-// fused taper -> 4096-point FFT -> |X|^2 -> weighted accumulation; part: spgram_fused_scratch_floats(nframes) floats
-size_t spgram_fused_scratch_floats(size_t nframes);
+// fused taper -> FFT -> |X|^2 -> weighted accumulation (nfft in {256,512,1024,2048,4096});
+// part: spgram_fused_scratch_floats(nfft, nframes) floats; twn = the plan's W_nfft table
+bool spgram_fused_supported(int nfft);
+size_t spgram_fused_scratch_floats(int nfft, size_t nframes);
 template <class T>
-int launch_spgram_fused4096(const T *win, const T *x, size_t x_len, const float *w, int wlen, long long first,
-                            int delay, size_t nframes, float alpha, float gamma, bool first_ever, const cf32 *tw4096,
-                            float *psd, float *part, hipStream_t st);
+int launch_spgram_fused(int nfft, const T *win, const T *x, size_t x_len, const float *w, int wlen, long long first,
+                        int delay, size_t nframes, float alpha, float gamma, bool first_ever, const cf32 *twn,
+                        float *psd, float *part, hipStream_t st);
 int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float *out, hipStream_t st);
 
 // ---- chan_kernels.hip ----------------------------------------------------------------------

@@ -8,7 +8,7 @@
 // per bin is the reference's).
 #include <cmath>
 
-#include "fft_core.hpp"
+#include "fft_radix.hpp"
 #include "kernels.hpp"
 
 namespace yagi {
@@ -150,6 +150,86 @@ spgram_fused4096_kernel(const T *__restrict__ win, const T *__restrict__ x, cons
     for (unsigned d = 0; d < 16; ++d) dst[t + 256u * d] = acc[d];
 }
 
+// The same for nfft = 256 M, M in {1, 2, 4, 8} (256 .. 2048): the workgroup transforms B = 16/M consecutive frames
+// at a time (fft_n256m_passes_to_regs: lane (tr, u) holds bins u + 16M i + 256 d of frame tr) and keeps one set of
+// accumulators per frame slot tr, so it writes B partial rows.
+template <class T, int M>
+__global__ void __launch_bounds__(256)
+spgram_fused_n256m_kernel(const T *__restrict__ win, const T *__restrict__ x, const float *__restrict__ w, int wlen,
+                          long long first, long long x_len, int delay, unsigned nframes, unsigned slab, float alpha,
+                          float log2_gamma, int first_ever, const float2 *__restrict__ tw, float *__restrict__ part) {
+    constexpr int N = 256 * M, LT = 16 * M, B = 16 / M;
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x, tr = t / LT, u = t % LT;
+    float wt[16];
+#pragma unroll
+    for (unsigned a = 0; a < 16; ++a) wt[a] = (int)(LT * a + u) < wlen ? w[LT * a + u] : 0.0f;
+    float acc[16];
+#pragma unroll
+    for (unsigned d = 0; d < 16; ++d) acc[d] = 0.0f;
+    const unsigned f0 = blockIdx.x * slab;                       // slab is a multiple of B
+    const unsigned f1 = (f0 + slab < nframes) ? f0 + slab : nframes;
+#pragma unroll 1
+    for (unsigned fi = f0; fi < f1; fi += B) {
+        unsigned z = 0;
+        asm volatile("" : "+s"(z));                              // see spgram_fused4096_kernel
+        const unsigned f = fi + tr;
+        const long long base0 = first + (long long)fi * delay - (wlen - 1);     // frame slot 0, sample 0
+        float2 v[16];
+        if (base0 >= 0 && base0 + (long long)(B - 1) * delay + N <= x_len && fi + B <= f1) {   // block-uniform
+            const T *src = x + base0 + (long long)tr * delay;
+#pragma unroll
+            for (unsigned a = 0; a < 16; ++a) {
+                const unsigned k = LT * a + u;
+                const float2 sv = sp_cx(src[k], wt[a]);
+                v[a] = (int)k < wlen ? sv : make_float2(0.f, 0.f);
+            }
+        } else {                                                 // window-reaching / last frames: rolled, through LDS
+#pragma unroll 1
+            for (int e = (int)t; e < 4096; e += 256) {
+                const int trr = e / N, k = e - trr * N;
+                float2 sv = make_float2(0.f, 0.f);
+                if (fi + trr < f1 && k < wlen) {
+                    const long long idx = base0 + (long long)trr * delay + k;
+                    sv = sp_cx((idx < 0) ? win[wlen + idx] : x[idx], w[k]);
+                }
+                lds[e] = sv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned a = 0; a < 16; ++a) v[a] = lds[tr * N + LT * a + u];
+            __syncthreads();
+        }
+        fft_n256m_passes_to_regs<-1, M>(v, lds, tw + z);
+        __syncthreads();                                         // lds is reused by the next iteration
+        float wgt = 0.0f;                                        // frame slots past the end contribute nothing
+        if (f < f1) {
+            wgt = exp2f(log2_gamma * (float)(nframes - 1 - f));
+            if (!(first_ever && f == 0)) wgt *= alpha;
+        }
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) acc[d] = fmaf(wgt, v[d].x * v[d].x + v[d].y * v[d].y, acc[d]);
+    }
+    float *dst = part + ((size_t)blockIdx.x * B + tr) * N + u;
+#pragma unroll
+    for (int i = 0; i < B; ++i)
+#pragma unroll
+        for (int d = 0; d < M; ++d) dst[LT * i + 256 * d] = acc[i * M + d];
+}
+
+// rows of partial sums -> rows / kSpFold rows (fixed order): out[c][i] = sum_{s in chunk c} part[s][i]
+constexpr unsigned kSpFold = 32;
+__global__ void __launch_bounds__(256)
+spgram_fold_kernel(const float *__restrict__ part, int nfft, unsigned nrows, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned c = blockIdx.y;
+    if (i >= nfft) return;
+    const unsigned s0 = c * kSpFold, s1 = (s0 + kSpFold < nrows) ? s0 + kSpFold : nrows;
+    float q = 0.0f;
+    for (unsigned s = s0; s < s1; ++s) q += part[(size_t)s * nfft + i];
+    out[(size_t)c * nfft + i] = q;
+}
+
 // psd[i] <- (first_ever ? 0 : gpow psd[i]) + sum_s part[s][i]; 4 partial sums per bin, combined in a fixed order
 __global__ void __launch_bounds__(256)
 spgram_sum_kernel(const float *__restrict__ part, int nfft, unsigned nslabs, float gpow, int first_ever,
@@ -201,34 +281,57 @@ int launch_spgram_accum(const cf32 *freq, int nfft, size_t nframes, float alpha,
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
-// fused nfft = 4096 path; part: spgram_fused_scratch_floats(nframes) floats
-static unsigned spgram_fused_slab(size_t nframes) {
+// fused paths: nfft = 4096 and nfft = 256 M (M in {1,2,4,8}); part: spgram_fused_scratch_floats(nfft, nframes) floats
+bool spgram_fused_supported(int nfft) { return nfft == 256 || nfft == 512 || nfft == 1024 || nfft == 2048 || nfft == 4096; }
+static unsigned spgram_fused_slab(int nfft, size_t nframes) {
+    const unsigned B = (unsigned)(4096 / nfft);                  // frames transformed together
     size_t sl = nframes / 1024;
-    return (unsigned)(sl < 4 ? 4 : (sl > 32 ? 32 : sl));
+    sl = sl < 4 ? 4 : (sl > 32 ? 32 : sl);
+    return (unsigned)((sl + B - 1) / B * B);
 }
-size_t spgram_fused_scratch_floats(size_t nframes) {
-    const unsigned slab = spgram_fused_slab(nframes);
-    return ((nframes + slab - 1) / slab) * (size_t)4096;
+size_t spgram_fused_scratch_floats(int nfft, size_t nframes) {
+    const unsigned slab = spgram_fused_slab(nfft, nframes);
+    const size_t rows_floats = ((nframes + slab - 1) / slab) * (size_t)4096;      // B rows of nfft floats per workgroup
+    return rows_floats + rows_floats / kSpFold + 4096;           // + the folded rows of the two-level sum
 }
 template <class T>
-int launch_spgram_fused4096(const T *win, const T *x, size_t x_len, const float *w, int wlen, long long first,
-                            int delay, size_t nframes, float alpha, float gamma, bool first_ever, const cf32 *tw4096,
-                            float *psd, float *part, hipStream_t st) {
+int launch_spgram_fused(int nfft, const T *win, const T *x, size_t x_len, const float *w, int wlen, long long first,
+                        int delay, size_t nframes, float alpha, float gamma, bool first_ever, const cf32 *twn,
+                        float *psd, float *part, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
     if (nframes > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "too many transforms in one call");
-    const unsigned slab = spgram_fused_slab(nframes);
-    const unsigned nslabs = (unsigned)((nframes + slab - 1) / slab);
+    const unsigned slab = spgram_fused_slab(nfft, nframes);
+    const unsigned nwg = (unsigned)((nframes + slab - 1) / slab);
     const float l2g = (float)std::log2((double)gamma);
-    spgram_fused4096_kernel<T><<<nslabs, 256, 0, st>>>(win, x, w, wlen, first, (long long)x_len, delay, (unsigned)nframes, slab, alpha, l2g,
-                                                      first_ever ? 1 : 0, reinterpret_cast<const float2 *>(tw4096), part);
+    const float2 *tw = reinterpret_cast<const float2 *>(twn);
+#define YG_SP_ARGS win, x, w, wlen, first, (long long)x_len, delay, (unsigned)nframes, slab, alpha, l2g, first_ever ? 1 : 0, tw, part
+    switch (nfft) {
+        case 4096: spgram_fused4096_kernel<T><<<nwg, 256, 0, st>>>(YG_SP_ARGS); break;
+        case 2048: spgram_fused_n256m_kernel<T, 8><<<nwg, 256, 0, st>>>(YG_SP_ARGS); break;
+        case 1024: spgram_fused_n256m_kernel<T, 4><<<nwg, 256, 0, st>>>(YG_SP_ARGS); break;
+        case 512: spgram_fused_n256m_kernel<T, 2><<<nwg, 256, 0, st>>>(YG_SP_ARGS); break;
+        case 256: spgram_fused_n256m_kernel<T, 1><<<nwg, 256, 0, st>>>(YG_SP_ARGS); break;
+        default: return fail(YAGI_ERR_INTERNAL, "spgram: no fused kernel for nfft %d", nfft);
+    }
+#undef YG_SP_ARGS
     YG_LAUNCH_CHECK();
-    spgram_sum_kernel<<<4096 / 64, 256, 0, st>>>(part, 4096, nslabs, (float)std::pow((double)gamma, (double)nframes),
-                                                first_ever ? 1 : 0, psd);
+    unsigned nrows = nwg * (unsigned)(4096 / nfft);
+    const float *rows = part;
+    if (nrows > 2 * kSpFold) {                                   // many rows: fold them 32 to 1 across the whole chip first
+        float *folded = part + (size_t)nrows * nfft;
+        const unsigned nf = (nrows + kSpFold - 1) / kSpFold;
+        spgram_fold_kernel<<<dim3((unsigned)((nfft + 255) / 256), nf), 256, 0, st>>>(part, nfft, nrows, folded);
+        YG_LAUNCH_CHECK();
+        rows = folded;
+        nrows = nf;
+    }
+    spgram_sum_kernel<<<(unsigned)(nfft / 64), 256, 0, st>>>(rows, nfft, nrows, (float)std::pow((double)gamma, (double)nframes),
+                                                            first_ever ? 1 : 0, psd);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
-template int launch_spgram_fused4096<float>(const float *, const float *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
-template int launch_spgram_fused4096<cf32>(const cf32 *, const cf32 *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
+template int launch_spgram_fused<float>(int, const float *, const float *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
+template int launch_spgram_fused<cf32>(int, const cf32 *, const cf32 *, size_t, const float *, int, long long, int, size_t, float, float, bool, const cf32 *, float *, float *, hipStream_t);
 
 int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float *out, hipStream_t st) {
     spgram_psd_kernel<<<sp_grid((size_t)nfft), 256, 0, st>>>(psd, nfft, scale, in_db ? 1 : 0, out);
