@@ -92,7 +92,8 @@ def test_firpfbch2_vs_oracle(ya, oracle, M, m):
 
 
 @pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200), (64, 8, 700),
-                                    (128, 8, 130)])
+                                    (128, 8, 130), (512, 2, 333), (512, 1, 64), (512, 4, 90), (1024, 1, 200), (1024, 2, 77),
+                                    (512, 2, 20000)])
 def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
     """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8,16}, even first step) incl. ragged tails"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
@@ -105,7 +106,7 @@ def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
     got = np.concatenate([q.analyzer_execute(x[: k * M2]), q.analyzer_execute(x[k * M2:])])
     assert rel_l2(got, want) <= 2e-6
     # sharded form on the same kernel
-    for R in (2, 8):
+    for R in ((2, 8) if ns <= 5000 else ()):
         dx = ya.DeviceArray.from_numpy(x)
         for r in (0, R - 1):
             qs = ya.FirPfbCh2(M, m, h)

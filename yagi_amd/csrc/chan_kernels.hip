@@ -703,6 +703,143 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     return YAGI_OK;
 }
 
+// firpfbch2, column-sliding form for wide banks (M = 512, 1024; 2m in {2, 4}): every lane owns M/256 windows
+// b = t + 256 cc (so the early/late-fed split b >= M/2 is uniform per cc), half tiles of HS = 4096/M steps.
+template <int P, int LGM>
+__global__ void __launch_bounds__(256)
+firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
+                      const float *__restrict__ h, const float2 *__restrict__ twM,
+                      float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 2*HS */) {
+    constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2, C = M / 256, HS = 4096 / M, TILE = 2 * HS, HP = HS / 2;
+    constexpr int R0 = LGM == 9 ? 8 : 16;
+    constexpr int nq = HS, lgnq = LGM == 9 ? 3 : 2;
+    constexpr int pitch = M + 32 / nq;
+    static_assert((TILE / 2) % P == 0, "ring slots must be static");       // pairs per tile = HS
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *va = reinterpret_cast<float2 *>(smem);               // [HS steps][pitch]
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;                               // M
+    const int t = threadIdx.x;
+    for (int e = t; e < M; e += 256) twl[e] = twM[e];
+    float h0r[C][P], h1[C][P];
+    int pos[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const int b = t + 256 * cc;
+        const int bpar = (b >= M2) ? 1 : 0;                      // uniform per cc (M2 is a multiple of 256)
+        pos[cc] = bpar ? (M - 1 - b) : (M2 - 1 - b);
+        const int i1 = (b - M2 + M) & (M - 1);
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            const int n0 = bpar ? (m + P - 1) % P : m;           // rotated for the late-fed half
+            h0r[cc][m] = h[b + n0 * M];
+            h1[cc][m] = h[i1 + m * M];
+        }
+    }
+    const float invM = 1.0f / (float)M;
+    const long long x_len = (long long)nsteps * M2;
+    const long long s_begin = (long long)blockIdx.x * run;       // even
+    const long long left = (long long)nsteps - s_begin;
+    const int nvalid = (int)(left < run ? left : run);
+    const bool full = nvalid == run;
+    float2 w[C][P];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const int bpar = (2 * cc >= C) ? 1 : 0;
+#pragma unroll
+        for (int n = 1; n <= P; ++n)                             // pairs -1 .. -P
+            w[cc][(P - n) % P] = load_hist(hist, hist_len, x, (s_begin - 2 * n + bpar) * M2 + pos[cc], x_len);
+    }
+    float2 xa[C][HP], xb[C][HP];
+    auto loadp = [&](float2 (&d)[C][HP], int st /* first step of the half tile */) {
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const int bpar = (2 * cc >= C) ? 1 : 0;
+            const float2 *xg = x + (s_begin + bpar) * M2 + pos[cc];          // + 2kk*M2 = kk*M
+#pragma unroll
+            for (int kk = 0; kk < HP; ++kk)
+                d[cc][kk] = (full || st + 2 * kk + bpar < nvalid) ? xg[(unsigned)(st / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+        }
+    };
+    float2 *yb = y + s_begin * M;
+    auto half_tile = [&](float2 (&xin)[C][HP], int st, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;               // ring slot of the half tile's first pair
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const bool late = 2 * cc >= C;
+#pragma unroll
+            for (int kk = 0; kk < HP; ++kk) {
+                const float2 old = w[cc][(S0 + kk) % P];
+                w[cc][(S0 + kk) % P] = late ? old : xin[cc][kk];  // even step: the late-fed half still sees the old sample
+                float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const float2 sv = w[cc][(S0 + kk - m + 4 * P) % P];
+                    a0.x = fmaf(sv.x, h0r[cc][m], a0.x);
+                    a0.y = fmaf(sv.y, h0r[cc][m], a0.y);
+                }
+                w[cc][(S0 + kk) % P] = xin[cc][kk];               // odd step: everybody is fed
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const float2 sv = w[cc][(S0 + kk - m + 4 * P) % P];
+                    a1.x = fmaf(sv.x, h1[cc][m], a1.x);
+                    a1.y = fmaf(sv.y, h1[cc][m], a1.y);
+                }
+                va[(2 * kk) * pitch + t + 256 * cc] = a0;
+                va[(2 * kk + 1) * pitch + t + 256 * cc] = a1;
+            }
+        }
+        if (st + TILE < run) loadp(xin, st + TILE);
+        __syncthreads();
+        stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        stockham_pass<8, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        stockham_pass<8, +1, true>(va, vb, M, R0 * 8, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HS * C; ++i) {
+            const int e = t + 256 * i;
+            const int q = e >> lgM, k = e & (M - 1);
+            if (full || st + q < nvalid) {
+                const float2 v = vb[q * pitch + k];
+                yb[((unsigned)(st + q) << lgM) + k] = make_float2(v.x * invM, v.y * invM);
+            }
+        }
+        __syncthreads();
+    };
+    loadp(xa, 0);
+    loadp(xb, HS);
+    for (int s0 = 0; s0 < run; s0 += TILE) {
+        half_tile(xa, s0, std::integral_constant<int, 0>{});
+        half_tile(xb, s0 + HS, std::integral_constant<int, HP>{});
+    }
+}
+
+template <int P, int LGM>
+static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, const float *h, const cf32 *twM,
+                                 cf32 *y, size_t nsteps, hipStream_t st) {
+    constexpr int M = 1 << LGM, HS = 4096 / M, TILE = 2 * HS;
+    size_t run = nsteps / (size_t)YG_COL_WGS;
+    run = run / TILE * TILE;
+    if (run < (size_t)TILE) run = TILE;
+    if (run > 512) run = 512;
+    const size_t nblk = (nsteps + run - 1) / run;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const size_t lds = (2 * (size_t)HS * (M + 32 / HS) + (size_t)M) * sizeof(float2);
+    static bool raised = false;
+    if (!raised) {
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_wide_kernel<P, LGM>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    firpfbch2_wide_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(
+        reinterpret_cast<const float2 *>(hist), hist_len, reinterpret_cast<const float2 *>(x), h,
+        reinterpret_cast<const float2 *>(twM), reinterpret_cast<float2 *>(y), nsteps, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
                      const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
                      hipStream_t st) {
@@ -712,6 +849,15 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
         return fail(YAGI_ERR_CONFIG, "firpfbch2: %d channels do not shard over %d ranks", M, nranks);
     const size_t lead = (size_t)(p - 1) * M + M2;
     if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
+    if (nranks == 1 && (step0 & 1) == 0 && nsteps >= 64 &&
+        ((M == 512 && (p == 2 || p == 4 || p == 8)) || (M == 1024 && (p == 2 || p == 4)))) {
+        if (M == 512)
+            return p == 2 ? launch_firpfbch2_wide<2, 9>(hist, hist_len, x, h, twM, y, nsteps, st)
+                 : p == 4 ? launch_firpfbch2_wide<4, 9>(hist, hist_len, x, h, twM, y, nsteps, st)
+                          : launch_firpfbch2_wide<8, 9>(hist, hist_len, x, h, twM, y, nsteps, st);
+        return p == 2 ? launch_firpfbch2_wide<2, 10>(hist, hist_len, x, h, twM, y, nsteps, st)
+                      : launch_firpfbch2_wide<4, 10>(hist, hist_len, x, h, twM, y, nsteps, st);
+    }
     if ((M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 && is_pow2(M / nranks)) {
 #define YG_COL2_CASE(PP)                                                                                          \
     case PP:                                                                                                      \
