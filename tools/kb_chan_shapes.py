@@ -13,7 +13,7 @@ x = torch.empty(n, dtype=torch.complex64, device=dev)
 y = torch.empty(2 * n, dtype=torch.complex64, device=dev)
 st = torch.cuda.current_stream()
 ya.gen_complex_dev(9, n, out=x, stream=st.cuda_stream)
-shapes = [(8, 4), (16, 4), (32, 8), (64, 8), (128, 4), (256, 4), (512, 4), (1024, 2), (48, 4), (100, 4)]
+shapes = [(8, 4), (16, 4), (32, 4), (64, 8), (128, 4), (256, 4), (512, 4), (1024, 2), (48, 4), (100, 4)]
 for M, m in shapes:
     for kind in ("ch", "ch2"):
         if kind == "ch":

@@ -164,6 +164,9 @@ firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
 // transforms together and stores [frame][channel] fully coalesced.
 // HBM traffic: 8 B/sample in (+ (p-1)/run halo, L2-served between the groups of one workgroup) + 8 out.
 // ---------------------------------------------------------------------------------------------
+// LDS slot pitch of one transform in the column kernels: M + 32/nq for nq <= 32 transforms in flight
+// (fft_radix.hpp), M + 1 (odd: the lanes of a pass, one transform apart, cover all banks) beyond
+__host__ __device__ constexpr int col_pitch(int M, int nq) { return M + (nq <= 32 ? 32 / nq : 1); }
 constexpr int kColTile = 16;
 constexpr int kColHalf = 8;
 #ifndef YG_COL_WGS
@@ -178,11 +181,12 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
                     const float *__restrict__ h, const float2 *__restrict__ twM,
                     float2 *__restrict__ y, size_t nframes, int run) {
     constexpr int M = 1 << LGM, lgM = LGM;
-    constexpr int R0 = LGM == 6 ? 8 : 16, R1 = M / R0;           // 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
+    // 8, 16: one pass; 32 = 8 x 4, 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
+    constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int G = 256 / M;
     constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;        // transforms per half tile (kColHalf = 8)
-    constexpr int pitch = M + 32 / nq;                          // = frfast_pitch(M, nq)
+    constexpr int pitch = col_pitch(M, nq);
     float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 frames][pitch]
     float2 *vb = va + nq * pitch;
     float2 *twl = vb + nq * pitch;                              // M
@@ -239,9 +243,12 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
         __syncthreads();
         stockham_pass<R0, -1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
         __syncthreads();
-        stockham_pass<R1, -1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
-        __syncthreads();
-        const float2 *res = va;
+        const float2 *res = vb;
+        if constexpr (R1 > 1) {
+            stockham_pass<R1, -1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+            __syncthreads();
+            res = va;
+        }
         // transform q = g'*8 + j is frame t + j of group g'
 #pragma unroll
         for (int i = 0; i < kColHalf; ++i) {
@@ -275,7 +282,7 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const unsigned grid = (unsigned)nblk;
-    const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
+    const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
         YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P, LGM>),
@@ -417,10 +424,13 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
         return p == 4 ? launch_firpfbch_wide<4, 10>(hist, x, h, twM, y, nframes, st)
                       : launch_firpfbch_wide<8, 10>(hist, x, h, twM, y, nframes, st);
     }
-    if ((M == 64 || M == 128 || M == 256) && nframes >= 64) {
+    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && nframes >= 64) {
 #define YG_COL_CASE(PP)                                                                              \
     case PP:                                                                                         \
-        return M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st)                 \
+        return M == 8 ? launch_firpfbch_col<PP, 3>(hist, x, h, twM, y, nframes, st)                  \
+             : M == 16 ? launch_firpfbch_col<PP, 4>(hist, x, h, twM, y, nframes, st)                 \
+             : M == 32 ? launch_firpfbch_col<PP, 5>(hist, x, h, twM, y, nframes, st)                 \
+             : M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st)                 \
              : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st)                \
                         : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st);
         switch (p) {
@@ -561,9 +571,9 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                      int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
-    constexpr int R0 = LGM == 6 ? 8 : 16, R1 = M / R0;
+    constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;   // 8, 16: one pass; 32 = 8 x 4
     constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;       // transforms in flight (kColHalf = 8)
-    constexpr int pitch = M + 32 / nq;                          // = frfast_pitch(M, nq)
+    constexpr int pitch = col_pitch(M, nq);
     const int Mr = SHARDED ? M / R : M;
     const int lgMr = 31 - __builtin_clz((unsigned)Mr);
     float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][pitch]
@@ -654,9 +664,12 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
         } else {
             stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
             __syncthreads();
-            stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
-            __syncthreads();
-            res = va;
+            res = vb;
+            if constexpr (R1 > 1) {
+                stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+                __syncthreads();
+                res = va;
+            }
         }
         for (int e = threadIdx.x; e < nq * Mr; e += 256) {
             const int q = e >> lgMr, k = e & (Mr - 1);
@@ -689,7 +702,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const unsigned grid = (unsigned)nblk;
-    const size_t lds = (2 * (size_t)G * kColHalf * frfast_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
+    const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
@@ -858,10 +871,14 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
         return p == 2 ? launch_firpfbch2_wide<2, 10>(hist, hist_len, x, h, twM, y, nsteps, st)
                       : launch_firpfbch2_wide<4, 10>(hist, hist_len, x, h, twM, y, nsteps, st);
     }
-    if ((M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 && is_pow2(M / nranks)) {
+    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 &&
+        is_pow2(M / nranks)) {
 #define YG_COL2_CASE(PP)                                                                                          \
     case PP:                                                                                                      \
-        return M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
+        return M == 8 ? launch_firpfbch2_col<PP, 3>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)       \
+             : M == 16 ? launch_firpfbch2_col<PP, 4>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
+             : M == 32 ? launch_firpfbch2_col<PP, 5>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
+             : M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
              : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)     \
                         : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st);
         switch (p) {
