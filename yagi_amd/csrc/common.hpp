@@ -28,9 +28,18 @@ int fail(int status, const char *fmt, ...);
                                 hipGetErrorString(e_), __FILE__, __LINE__);                   \
     } while (0)
 
+// Propagate a failed status.  It is also the exception barrier of the C ABI: the entry points reach every
+// allocating member function (init, clone, prepare_*, ...) through YG_TRY, so a std::bad_alloc or any other
+// C++ exception raised below is turned into YAGI_ERR_INTERNAL here instead of unwinding into a C / Rust caller.
+int api_exception() noexcept;
 #define YG_TRY(expr)                                                                          \
     do {                                                                                      \
-        int s_ = (expr);                                                                      \
+        int s_;                                                                               \
+        try {                                                                                 \
+            s_ = (expr);                                                                      \
+        } catch (...) {                                                                       \
+            s_ = ::yagi::api_exception();                                                     \
+        }                                                                                     \
         if (s_ != YAGI_OK) return s_;                                                         \
     } while (0)
 

@@ -28,6 +28,22 @@ int fail(int status, const char *fmt, ...) {
     return status;
 }
 
+// translate the exception in flight (called from a catch (...) block) into a status + message
+int api_exception() noexcept {
+    const char *what = "unexpected C++ exception";
+    std::string msg;
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        what = "out of host memory";
+    } catch (const std::exception &e) {
+        try { msg = std::string("unexpected C++ exception: ") + e.what(); what = msg.c_str(); } catch (...) {}
+    } catch (...) {
+    }
+    try { g_last_error = what; } catch (...) {}
+    return YAGI_ERR_INTERNAL;
+}
+
 // ---- Kaiser design, single precision like the reference -----------------------------------
 // ln Gamma(z): recursion below 10, Stirling-type series above (math/gamma.rs:7-22)
 static float ln_gamma(float z) {
