@@ -44,7 +44,7 @@ def test_fft_config(ya):
     with pytest.raises(ya.ConfigError):
         ya.Fft(0, ya.Direction.Forward)
     with pytest.raises(ya.ConfigError):
-        ya.Fft(1 << 20, ya.Direction.Forward)          # documented size limit
+        ya.Fft(1 << 25, ya.Direction.Forward)          # documented size limit (2^24)
     f = ya.Fft(16, ya.Direction.Forward)
     with pytest.raises(ya.ConfigError):                # the reference panics (copy_from_slice)
         f.run(np.zeros(15, np.complex64))
@@ -135,3 +135,26 @@ def test_fft_large_batch_on_device(ya, oracle, n):
     for b in (0, 1, 5, batch // 2, batch - 2, batch - 1):
         truth = oracle.dft_f64(dx.to_numpy(n, offset=b * n))
         assert rel_l2(dy.to_numpy(n, offset=b * n), truth) <= 1e-5, b
+
+
+@pytest.mark.parametrize("n", [16384, 32768, 1 << 20, 10000, 12289, 8193, 100003])
+@pytest.mark.parametrize("direction", ["Forward", "Backward"])
+def test_fft_beyond_one_workgroup(ya, n, direction):
+    """n > 8192: powers of two by the four-step form (transposes around the register kernels), every other size by
+    Bluestein over a power of two (itself four-step above 8192).  Truth: numpy's f64 FFT of the same f32 samples."""
+    rng = np.random.default_rng(n)
+    batch = 2
+    x = ((rng.standard_normal(batch * n) + 1j * rng.standard_normal(batch * n)) * np.sqrt(0.5)).astype(np.complex64)
+    d = ya.Direction[direction]
+    got = ya.Fft(n, d).run_batch(x)
+    for b in range(batch):
+        xb = x[b * n:(b + 1) * n].astype(np.complex128)
+        truth = np.fft.fft(xb) if d == ya.Direction.Forward else np.fft.ifft(xb) * n
+        assert rel_l2(got[b], truth) <= 1e-5, b
+
+
+def test_fft_size_limits(ya):
+    with pytest.raises(ya.ConfigError):
+        ya.Fft((1 << 24) + 1, ya.Direction.Forward)         # not a power of two and 2n-1 > 2^24
+    with pytest.raises(ya.ConfigError):
+        ya.Fft(1 << 25, ya.Direction.Forward)

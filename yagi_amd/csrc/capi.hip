@@ -303,6 +303,8 @@ struct FftPlan {
     DevBuf tw;
     Workspace ws;
     DevBuf bs_w, bs_bf, bs_twf, bs_twb, bs_scratch;      // Bluestein resources (sizes with a large prime factor)
+    std::unique_ptr<FftPlan> bs_fwd, bs_bwd;             // Bluestein over m > 8192: the m-point plans
+    DevBuf fs_tw1, fs_tw2, fs_scratch;                   // four-step resources (powers of two above 8192)
 };
 
 // radix list of the mixed-radix kernel: the power of two in as few passes as radix <= 16 allows (bits spread
@@ -341,55 +343,88 @@ static int make_twiddles(int n, int dir, DevBuf &buf, bool half_too = false) {
 static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     if (n == 0) return fail(YAGI_ERR_CONFIG, "fft length must be greater than zero");
     if (dir != YAGI_FFT_FORWARD && dir != YAGI_FFT_BACKWARD) return fail(YAGI_ERR_CONFIG, "bad fft direction");
-    if (n > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft length %zu not supported (max %d)", n, kFftMaxLds);
+    const bool pow2 = (n & (n - 1)) == 0;
+    if (n > kFftMaxPow2 || (!pow2 && 2 * n - 1 > kFftMaxPow2))
+        return fail(YAGI_ERR_CONFIG, "fft length %zu not supported (powers of two up to %zu, other sizes up to %zu)", n,
+                    kFftMaxPow2, kFftMaxPow2 / 2);
     YG_TRY(require_device());
     p.d.n = (int)n;
     p.d.dir = dir;
-    factorize((int)n, p.d.fac, p.d.nfac);
-    YG_TRY(make_twiddles((int)n, dir, p.tw, n == 8192));
-    p.d.tw = p.tw.as<cf32>();
-    // A prime factor p costs O(n p) per transform in the mixed-radix kernel's direct-sum pass; beyond 89 (measured crossover; and
-    // while the 2n-1 point convolution fits the largest power-of-two kernel) Bluestein's chirp-z form is used:
-    //   X[k] = w[k] sum_j (x[j] w[j]) conj(w[k-j]),  w[k] = e^{-+ j pi k^2 / n}
+    if (pow2 && n > (size_t)kFftMaxLds) {
+        // four-step: n = n1 n2 with n1 >= n2, both in [128, 4096]
+        int lg = 0;
+        while (((size_t)1 << lg) < n) ++lg;
+        const int n1 = 1 << ((lg + 1) / 2), n2 = 1 << (lg / 2);
+        YG_TRY(make_twiddles(n1, dir, p.fs_tw1));
+        YG_TRY(make_twiddles(n2, dir, p.fs_tw2));
+        size_t chunk = ((size_t)1 << 23) / n;                  // 2 x 64 MiB of scratch
+        if (chunk < 1) chunk = 1;
+        YG_TRY(p.fs_scratch.alloc(2 * chunk * n * sizeof(cf32)));
+        p.d.fs_n1 = n1;
+        p.d.fs_n2 = n2;
+        p.d.fs_tw1 = p.fs_tw1.as<cf32>();
+        p.d.fs_tw2 = p.fs_tw2.as<cf32>();
+        p.d.fs_scratch = p.fs_scratch.as<cf32>();
+        p.d.fs_chunk = (int)chunk;
+        return YAGI_OK;
+    }
     int maxp = 1;
-    for (int i = 0; i < p.d.nfac; ++i) maxp = p.d.fac[i] > maxp ? p.d.fac[i] : maxp;
+    if (n <= (size_t)kFftMaxLds) {
+        factorize((int)n, p.d.fac, p.d.nfac);
+        YG_TRY(make_twiddles((int)n, dir, p.tw, n == 8192));
+        p.d.tw = p.tw.as<cf32>();
+        for (int i = 0; i < p.d.nfac; ++i) maxp = p.d.fac[i] > maxp ? p.d.fac[i] : maxp;
+    }
+    // A prime factor p costs O(n p) per transform in the mixed-radix kernel's direct-sum pass; beyond 89 (measured
+    // crossover) -- and for every size that does not fit the one-kernel paths -- Bluestein's chirp-z form is used:
+    //   X[k] = w[k] sum_j (x[j] w[j]) conj(w[k-j]),  w[k] = e^{-+ j pi k^2 / n}
     static const int bs_minp = getenv("YAGI_HIP_BLUESTEIN_MIN_PRIME") ? atoi(getenv("YAGI_HIP_BLUESTEIN_MIN_PRIME")) : 89;
-    if (maxp > bs_minp && 2 * n - 1 <= (size_t)kFftMaxLds) {
-        int m = 1;
-        while ((size_t)m < 2 * n - 1) m *= 2;
+    if (n > (size_t)kFftMaxLds || maxp > bs_minp) {
+        size_t m = 1;
+        while (m < 2 * n - 1) m *= 2;
         if (m < 256) m = 256;
         const double sgn = (dir == YAGI_FFT_FORWARD) ? -1.0 : 1.0;
-        std::vector<cf32> w(n), b((size_t)m, cf32{0.f, 0.f});
+        std::vector<cf32> w(n), b(m, cf32{0.f, 0.f});
         for (size_t k = 0; k < n; ++k) {
             const unsigned long long k2 = ((unsigned long long)k * k) % (2ull * n);      // exact phase index
             const double a = sgn * M_PI * (double)k2 / (double)n;
             w[k] = cf32{(float)std::cos(a), (float)std::sin(a)};
             const cf32 cw{w[k].re, -w[k].im};
             b[k] = cw;
-            if (k) b[(size_t)m - k] = cw;
+            if (k) b[m - k] = cw;
         }
         YG_TRY(p.bs_w.alloc(n * sizeof(cf32)));
         YG_TRY(upload(p.bs_w.p, w.data(), n * sizeof(cf32), nullptr));
-        YG_TRY(make_twiddles(m, YAGI_FFT_FORWARD, p.bs_twf, m == 8192));
-        YG_TRY(make_twiddles(m, YAGI_FFT_BACKWARD, p.bs_twb, m == 8192));
-        const int chunk = (1 << 21) / m;                       // 2 x 16 MiB of scratch
-        YG_TRY(p.bs_scratch.alloc(2 * (size_t)chunk * m * sizeof(cf32)));
-        YG_TRY(p.bs_bf.alloc((size_t)m * sizeof(cf32)));
-        // FFT_m of the chirp filter by the device transform itself
-        FftPlanDev f;
-        f.n = m;
-        f.dir = YAGI_FFT_FORWARD;
-        f.tw = p.bs_twf.as<cf32>();
-        YG_TRY(upload(p.bs_scratch.p, b.data(), (size_t)m * sizeof(cf32), nullptr));
+        size_t chunk = ((size_t)1 << 21) / m;                  // 2 x 16 MiB of scratch (more for one big transform)
+        if (chunk < 1) chunk = 1;
+        YG_TRY(p.bs_scratch.alloc(2 * chunk * m * sizeof(cf32)));
+        YG_TRY(p.bs_bf.alloc(m * sizeof(cf32)));
+        FftPlanDev f;                                          // FFT_m of the chirp filter by the device transform itself
+        if (m > (size_t)kFftMaxLds) {
+            p.bs_fwd = std::make_unique<FftPlan>();
+            p.bs_bwd = std::make_unique<FftPlan>();
+            YG_TRY(fft_plan_init(*p.bs_fwd, m, YAGI_FFT_FORWARD));
+            YG_TRY(fft_plan_init(*p.bs_bwd, m, YAGI_FFT_BACKWARD));
+            p.d.bs_fwd = &p.bs_fwd->d;
+            p.d.bs_bwd = &p.bs_bwd->d;
+            f = p.bs_fwd->d;
+        } else {
+            YG_TRY(make_twiddles((int)m, YAGI_FFT_FORWARD, p.bs_twf, m == 8192));
+            YG_TRY(make_twiddles((int)m, YAGI_FFT_BACKWARD, p.bs_twb, m == 8192));
+            f.n = (int)m;
+            f.dir = YAGI_FFT_FORWARD;
+            f.tw = p.bs_twf.as<cf32>();
+        }
+        YG_TRY(upload(p.bs_scratch.p, b.data(), m * sizeof(cf32), nullptr));
         YG_TRY(launch_fft_batch(f, p.bs_scratch.as<cf32>(), p.bs_bf.as<cf32>(), 1, nullptr));
         YG_HIP(hipStreamSynchronize(nullptr));
-        p.d.bs_m = m;
+        p.d.bs_m = (int)m;
         p.d.bs_w = p.bs_w.as<cf32>();
         p.d.bs_bf = p.bs_bf.as<cf32>();
         p.d.bs_twf = p.bs_twf.as<cf32>();
         p.d.bs_twb = p.bs_twb.as<cf32>();
         p.d.bs_scratch = p.bs_scratch.as<cf32>();
-        p.d.bs_chunk = chunk;
+        p.d.bs_chunk = (int)chunk;
     }
     return YAGI_OK;
 }

@@ -200,14 +200,79 @@ bluestein_mul_kernel(float2 *__restrict__ f, const float2 *__restrict__ bf, int 
         f[e] = cmul(f[e], bf[e & (size_t)(m - 1)]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Powers of two above 8192: four-step form.  x viewed as [n1][n2] (n = n1 n2, both <= 4096):
+//   A[n2][n1] = x^T;  B = FFT_n1 of each row;  C[k1][n2] = B[n2][k1] W_n^{n2 k1};  D = FFT_n2 of each row;
+//   X[k2 n1 + k1] = D[k1][k2]  (third transpose).
+// Five HBM round trips per point instead of one -- the price of not fitting a workgroup; the row transforms
+// are the register kernels above.  The twiddle angle is evaluated in double per element (exact index n2 k1 < n).
+// ---------------------------------------------------------------------------------------------
+template <bool TWIDDLE>
+__global__ void __launch_bounds__(256)
+fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int rows, int cols, double tw_step) {
+    __shared__ float2 tile[32][33];
+    const size_t mat = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int r = r0 + ty + j, c = c0 + tx;                           // rows, cols are multiples of 32
+        float2 v = in[mat + (size_t)r * cols + c];
+        if (TWIDDLE) {
+            double sn, cs;
+            sincospi(tw_step * (double)((long long)r * c), &sn, &cs);     // tw_step = -+2/n
+            v = cmul(v, make_float2((float)cs, (float)sn));
+        }
+        tile[ty + j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j, r = r0 + tx;
+        out[mat + (size_t)c * rows + r] = tile[tx][ty + j];
+    }
+}
+
+static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    const int n1 = p.fs_n1, n2 = p.fs_n2;
+    const size_t n = (size_t)p.n;
+    FftPlanDev f1, f2;
+    f1.n = n1; f1.dir = p.dir; f1.tw = p.fs_tw1;
+    f2.n = n2; f2.dir = p.dir; f2.tw = p.fs_tw2;
+    float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch), *s1 = s0 + (size_t)p.fs_chunk * n;
+    const double tw_step = (p.dir == YAGI_FFT_FORWARD ? -2.0 : 2.0) / (double)n;
+    for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.fs_chunk) {
+        const unsigned nb = (unsigned)((batch - b0) < (size_t)p.fs_chunk ? (batch - b0) : (size_t)p.fs_chunk);
+        const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
+        float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
+        // x[n1][n2] -> A[n2][n1]
+        fft_transpose_kernel<false><<<dim3(n2 / 32, n1 / 32, nb), 256, 0, st>>>(src, s0, n1, n2, 0.0);
+        YG_LAUNCH_CHECK();
+        YG_TRY(launch_fft_batch(f1, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n2, st));
+        // B[n2][k1] -> C[k1][n2] with W_n^{n2 k1}
+        fft_transpose_kernel<true><<<dim3(n1 / 32, n2 / 32, nb), 256, 0, st>>>(s1, s0, n2, n1, tw_step);
+        YG_LAUNCH_CHECK();
+        YG_TRY(launch_fft_batch(f2, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n1, st));
+        // D[k1][k2] -> X[k2][k1]
+        fft_transpose_kernel<false><<<dim3(n2 / 32, n1 / 32, nb), 256, 0, st>>>(s1, dst, n1, n2, 0.0);
+        YG_LAUNCH_CHECK();
+    }
+    return YAGI_OK;
+}
+
 static int launch_fft_bluestein(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int m = p.bs_m;
     FftPlanDev fwd, bwd;
-    fwd.n = bwd.n = m;
-    fwd.dir = YAGI_FFT_FORWARD;
-    bwd.dir = YAGI_FFT_BACKWARD;
-    fwd.tw = p.bs_twf;
-    bwd.tw = p.bs_twb;
+    if (p.bs_fwd && p.bs_bwd) {          // m > 8192: full plans with their own (four-step) resources
+        fwd = *p.bs_fwd;
+        bwd = *p.bs_bwd;
+    } else {
+        fwd.n = bwd.n = m;
+        fwd.dir = YAGI_FFT_FORWARD;
+        bwd.dir = YAGI_FFT_BACKWARD;
+        fwd.tw = p.bs_twf;
+        bwd.tw = p.bs_twb;
+    }
     float2 *s0 = reinterpret_cast<float2 *>(p.bs_scratch), *s1 = s0 + (size_t)p.bs_chunk * m;
     const float2 *w = reinterpret_cast<const float2 *>(p.bs_w);
     for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.bs_chunk) {
@@ -241,8 +306,9 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         YG_LAUNCH_CHECK();
         return YAGI_OK;
     }
-    if (p.n > kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %d not supported (max %d)", p.n, kFftMaxLds);
     if (p.bs_m) return launch_fft_bluestein(p, in, out, batch, st);
+    if (p.fs_n1) return launch_fft_four_step(p, in, out, batch, st);
+    if (p.n > kFftMaxLds) return fail(YAGI_ERR_INTERNAL, "fft size %d has no plan resources", p.n);
     if (p.n == 8192) {
         if (batch > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
         if (p.dir == YAGI_FFT_FORWARD) fft8192_kernel<-1><<<(unsigned)batch, 256, 0, st>>>(fin, fout, tw);

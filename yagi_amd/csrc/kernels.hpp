@@ -102,8 +102,15 @@ struct FftPlanDev {
     const cf32 *bs_twb = nullptr;
     cf32 *bs_scratch = nullptr;      // 2 * bs_chunk * m points
     int bs_chunk = 0;                // transforms per pass through the scratch
+    const FftPlanDev *bs_fwd = nullptr, *bs_bwd = nullptr;   // host pointers: the m-point plans (own resources when m > 8192)
+    // four-step form for powers of two above 8192: n = n1 * n2, column transforms, twiddle, row transforms
+    int fs_n1 = 0, fs_n2 = 0;        // 0 = not used
+    const cf32 *fs_tw1 = nullptr, *fs_tw2 = nullptr;          // W_n1, W_n2 tables (sign per direction)
+    cf32 *fs_scratch = nullptr;      // 2 * fs_chunk * n points
+    int fs_chunk = 0;
 };
 constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
+constexpr size_t kFftMaxPow2 = (size_t)1 << 24;    // largest power of two (four-step); any other n up to 2^23 (Bluestein)
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st);
 int launch_fft_shift(cf32 *buf, size_t n, size_t batch, hipStream_t st);
 
