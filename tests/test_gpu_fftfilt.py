@@ -51,7 +51,7 @@ def test_fftfilt_config(ya):
     with pytest.raises(ya.ConfigError):
         ya.FftFilt("rrrf", h2, 7)
     with pytest.raises(ya.ConfigError):
-        ya.FftFilt("rrrf", h2, 1 << 20)                # engine limit: 2n <= 8192
+        ya.FftFilt("rrrf", h2, 1 << 22)                # engine limit: 2n <= 2^22
     f = ya.FftFilt("rrrf", h2, 64)
     f.set_scale(3.0)
     assert abs(f.get_scale() - 3.0) < 1e-6
@@ -77,7 +77,8 @@ def test_fftfilt_copy(ya, kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("L,n", [(1, 1), (5, 4), (64, 64), (256, 2048), (257, 256), (1000, 4096), (100, 100), (2049, 2048),
-                                 (2050, 2049), (3000, 4096)])      # > 2049 taps: the five-stage overlap-add path
+                                 (2050, 2049), (3000, 4096), (2500, 5000),
+                                 (9000, 16384)])      # > 2049 taps: the five-stage overlap-add path (2n > 8192: Bluestein / four-step)
 def test_fftfilt_equals_direct_form(ya, oracle, kind, L, n):
     """fast convolution == firfilt (f64 truth) for ragged block counts and carried state"""
     rng = np.random.default_rng(L + n)

@@ -110,7 +110,7 @@ def test_spgram_config_and_estimate(ya, oracle):
     for bad in [lambda: ya.Spgram(1, W.Hamming, 1, 1), lambda: ya.Spgram(64, W.Hamming, 65, 1),
                 lambda: ya.Spgram(64, W.Hamming, 0, 1), lambda: ya.Spgram(64, W.Hamming, 32, 0),
                 lambda: ya.Spgram(64, W.Kaiser, 33, 1), lambda: ya.Spgram(64, W.Unknown, 32, 1),
-                lambda: ya.Spgram.default(1), lambda: ya.Spgram(1 << 15, W.Hamming, 64, 16)]:
+                lambda: ya.Spgram.default(1), lambda: ya.Spgram(1 << 21, W.Hamming, 64, 16)]:
         with pytest.raises(ya.ConfigError):
             bad()
     with pytest.raises(ya.ValueError_):                 # windows::kbd rejects odd lengths (windows.rs:161-163)
@@ -170,3 +170,17 @@ def test_spgram_fused_vs_oracle(ya, oracle, dtype, nfft, shape):
     a, b = q.get_psd_mag(), ref.get_psd_mag()
     assert np.max(np.abs(a - b) / b) <= 1e-3
     assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-5
+
+
+@pytest.mark.parametrize("nfft,wlen,delay", [(16384, 16384, 8192), (10000, 7000, 3333)])
+def test_spgram_large_nfft_vs_oracle(ya, oracle, nfft, wlen, delay):
+    """transforms beyond one workgroup (four-step / Bluestein plans) through the unfused pipeline"""
+    n = 12 * nfft + 77
+    x = noise(oracle, n) * np.float32(1e-2)
+    ref = oracle.Spgram(nfft, 2, wlen, delay)
+    q = ya.Spgram(nfft, ya.WindowType.Hann, wlen, delay)
+    ref.write(x)
+    q.write(x)
+    assert q.get_num_transforms() == ref.num_transforms
+    a, b = q.get_psd_mag(), ref.get_psd_mag()
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 5e-5

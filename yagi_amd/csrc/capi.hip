@@ -1432,7 +1432,7 @@ struct SpgramObj {
             return fail(YAGI_ERR_CONFIG, "KBD window length must be even");
         if (delay_ == 0) return fail(YAGI_ERR_CONFIG, "delay must be greater than 0");
         if (wtype_ < 1 || wtype_ > 9) return fail(YAGI_ERR_CONFIG, "unknown window type");
-        if (nfft_ > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "fft size %zu not supported (max %d)", nfft_, kFftMaxLds);
+        if (nfft_ > ((size_t)1 << 20)) return fail(YAGI_ERR_CONFIG, "fft size %zu not supported (max %d)", nfft_, 1 << 20);
         YG_TRY(require_device());
         nfft = (int)nfft_; wtype = wtype_; wlen = (int)wlen_; delay = (int)delay_;
         // taper (spgram.rs:93-119): window, then normalise to unit energy
@@ -1496,7 +1496,8 @@ struct SpgramObj {
             }
             return YAGI_OK;
         }
-        const size_t chunk = 8192;
+        size_t chunk = ((size_t)1 << 25) / (size_t)nfft;          // transforms per batch: 2 x 256 MiB of frames at most
+        chunk = chunk < 1 ? 1 : (chunk > 8192 ? 8192 : chunk);
         for (size_t f0 = 0; f0 < nframes; f0 += chunk) {
             const size_t nf = (nframes - f0) < chunk ? (nframes - f0) : chunk;
             YG_TRY(tbuf.ensure(nf * (size_t)nfft * sizeof(cf32)));
@@ -1708,7 +1709,7 @@ struct FftFiltObj {
         if (h_len == 0) return fail(YAGI_ERR_CONFIG, "filter length must be greater than zero");
         if (nn < h_len - 1) return fail(YAGI_ERR_CONFIG, "block length must be greater than h_len-1 (%zu)", h_len - 1);
         if (nn == 0) return fail(YAGI_ERR_CONFIG, "block length must be greater than zero");
-        if (2 * nn > (size_t)kFftMaxLds) return fail(YAGI_ERR_CONFIG, "block length %zu not supported (2n <= %d)", nn, kFftMaxLds);
+        if (2 * nn > ((size_t)1 << 22)) return fail(YAGI_ERR_CONFIG, "block length %zu not supported (2n <= %d)", nn, 1 << 22);
         YG_TRY(require_device());
         h.assign(hh, hh + h_len);
         n = (int)nn;
