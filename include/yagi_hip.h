@@ -326,9 +326,9 @@ int yagi_hip_firfilt_cccf_set_kernel(yagi_hip_firfilt_cccf q, int choice);
  *   fft_run      fft_run(input, output, dir)   :66-69   plan + run in one call
  * Sizes: every n up to 2^23, powers of two up to 2^24.  Powers of two 256..8192: register kernels (one HBM
  * round trip); other n <= 8192: mixed-radix Stockham passes in LDS (register butterflies for 2/3/4/5/7/8/16,
- * direct sums for other primes up to 89); powers of two above 8192: four-step form (three transposes around the
- * register kernels); everything else -- a prime factor > 89, or n > 8192 that is not a power of two --
- * Bluestein's chirp-z form over a power of two.  Larger n returns CONFIG.  Plans with scratch (Bluestein,
+ * direct sums for other primes up to 89); n > 8192 that splits as n1 n2 with both factors <= 8192 and 89-smooth
+ * (every power of two, 10000, 48000, ...): four-step form (three transposes around the sub-transforms);
+ * everything else -- a prime factor > 89 -- Bluestein's chirp-z form over a power of two.  Larger n returns CONFIG.  Plans with scratch (Bluestein,
  * four-step) are not safe for concurrent run() calls on one handle. */
 typedef struct yagi_hip_fft_s *yagi_hip_fft;
 int yagi_hip_fft_create(size_t n, int direction, yagi_hip_fft *plan);

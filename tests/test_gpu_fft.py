@@ -137,7 +137,7 @@ def test_fft_large_batch_on_device(ya, oracle, n):
         assert rel_l2(dy.to_numpy(n, offset=b * n), truth) <= 1e-5, b
 
 
-@pytest.mark.parametrize("n", [16384, 32768, 1 << 20, 10000, 12289, 8193, 100003])
+@pytest.mark.parametrize("n", [16384, 32768, 1 << 20, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4])
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_beyond_one_workgroup(ya, n, direction):
     """n > 8192: powers of two by the four-step form (transposes around the register kernels), every other size by

@@ -304,7 +304,8 @@ struct FftPlan {
     Workspace ws;
     DevBuf bs_w, bs_bf, bs_twf, bs_twb, bs_scratch;      // Bluestein resources (sizes with a large prime factor)
     std::unique_ptr<FftPlan> bs_fwd, bs_bwd;             // Bluestein over m > 8192: the m-point plans
-    DevBuf fs_tw1, fs_tw2, fs_scratch;                   // four-step resources (powers of two above 8192)
+    std::unique_ptr<FftPlan> fs_p1, fs_p2;               // four-step: the n1- and n2-point plans
+    DevBuf fs_scratch;
 };
 
 // radix list of the mixed-radix kernel: the power of two in as few passes as radix <= 16 allows (bits spread
@@ -350,23 +351,34 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     YG_TRY(require_device());
     p.d.n = (int)n;
     p.d.dir = dir;
-    if (pow2 && n > (size_t)kFftMaxLds) {
-        // four-step: n = n1 n2 with n1 >= n2, both in [128, 4096]
-        int lg = 0;
-        while (((size_t)1 << lg) < n) ++lg;
-        const int n1 = 1 << ((lg + 1) / 2), n2 = 1 << (lg / 2);
-        YG_TRY(make_twiddles(n1, dir, p.fs_tw1));
-        YG_TRY(make_twiddles(n2, dir, p.fs_tw2));
-        size_t chunk = ((size_t)1 << 23) / n;                  // 2 x 64 MiB of scratch
-        if (chunk < 1) chunk = 1;
-        YG_TRY(p.fs_scratch.alloc(2 * chunk * n * sizeof(cf32)));
-        p.d.fs_n1 = n1;
-        p.d.fs_n2 = n2;
-        p.d.fs_tw1 = p.fs_tw1.as<cf32>();
-        p.d.fs_tw2 = p.fs_tw2.as<cf32>();
-        p.d.fs_scratch = p.fs_scratch.as<cf32>();
-        p.d.fs_chunk = (int)chunk;
-        return YAGI_OK;
+    if (n > (size_t)kFftMaxLds) {
+        // four-step: n = n1 n2, both <= 8192, as balanced as the divisors of n allow, and neither with a prime factor
+        // that would send it to Bluestein (> 89); a size without such a split (a large prime factor) takes Bluestein
+        size_t n2 = 0;
+        auto smooth = [](size_t v) {
+            for (size_t q = 2; q <= 89 && v > 1; ++q) while (v % q == 0) v /= q;
+            return v == 1;
+        };
+        for (size_t d = (size_t)std::sqrt((double)n) + 1; d >= 2; --d)
+            if (n % d == 0 && n / d <= (size_t)kFftMaxLds && d <= (size_t)kFftMaxLds && smooth(d) && smooth(n / d)) { n2 = d; break; }
+        if (n2) {
+            const size_t n1 = n / n2;
+            p.fs_p1 = std::make_unique<FftPlan>();
+            p.fs_p2 = std::make_unique<FftPlan>();
+            YG_TRY(fft_plan_init(*p.fs_p1, n1, dir));
+            YG_TRY(fft_plan_init(*p.fs_p2, n2, dir));
+            size_t chunk = ((size_t)1 << 23) / n;              // 2 x 64 MiB of scratch
+            if (chunk < 1) chunk = 1;
+            YG_TRY(p.fs_scratch.alloc(2 * chunk * n * sizeof(cf32)));
+            p.d.fs_n1 = (int)n1;
+            p.d.fs_n2 = (int)n2;
+            p.d.fs_p1 = &p.fs_p1->d;
+            p.d.fs_p2 = &p.fs_p2->d;
+            p.d.fs_scratch = p.fs_scratch.as<cf32>();
+            p.d.fs_chunk = (int)chunk;
+            return YAGI_OK;
+        }
+        if (pow2) return fail(YAGI_ERR_INTERNAL, "no four-step split for %zu", n);
     }
     int maxp = 1;
     if (n <= (size_t)kFftMaxLds) {

@@ -201,7 +201,7 @@ bluestein_mul_kernel(float2 *__restrict__ f, const float2 *__restrict__ bf, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Powers of two above 8192: four-step form.  x viewed as [n1][n2] (n = n1 n2, both <= 4096):
+// n = n1 n2 above 8192 points (n1, n2 <= 8192): four-step form.  x viewed as [n1][n2]:
 //   A[n2][n1] = x^T;  B = FFT_n1 of each row;  C[k1][n2] = B[n2][k1] W_n^{n2 k1};  D = FFT_n2 of each row;
 //   X[k2 n1 + k1] = D[k1][k2]  (third transpose).
 // Five HBM round trips per point instead of one -- the price of not fitting a workgroup; the row transforms
@@ -216,45 +216,46 @@ fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, in
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                // 32 x 8
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
-        const int r = r0 + ty + j, c = c0 + tx;                           // rows, cols are multiples of 32
-        float2 v = in[mat + (size_t)r * cols + c];
-        if (TWIDDLE) {
-            double sn, cs;
-            sincospi(tw_step * (double)((long long)r * c), &sn, &cs);     // tw_step = -+2/n
-            v = cmul(v, make_float2((float)cs, (float)sn));
+        const int r = r0 + ty + j, c = c0 + tx;
+        if (r < rows && c < cols) {
+            float2 v = in[mat + (size_t)r * cols + c];
+            if (TWIDDLE) {
+                double sn, cs;
+                sincospi(tw_step * (double)((long long)r * c), &sn, &cs);     // tw_step = -+2/n
+                v = cmul(v, make_float2((float)cs, (float)sn));
+            }
+            tile[ty + j][tx] = v;
         }
-        tile[ty + j][tx] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         const int c = c0 + ty + j, r = r0 + tx;
-        out[mat + (size_t)c * rows + r] = tile[tx][ty + j];
+        if (r < rows && c < cols) out[mat + (size_t)c * rows + r] = tile[tx][ty + j];
     }
 }
 
 static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int n1 = p.fs_n1, n2 = p.fs_n2;
     const size_t n = (size_t)p.n;
-    FftPlanDev f1, f2;
-    f1.n = n1; f1.dir = p.dir; f1.tw = p.fs_tw1;
-    f2.n = n2; f2.dir = p.dir; f2.tw = p.fs_tw2;
+    const FftPlanDev &f1 = *p.fs_p1, &f2 = *p.fs_p2;
     float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch), *s1 = s0 + (size_t)p.fs_chunk * n;
     const double tw_step = (p.dir == YAGI_FFT_FORWARD ? -2.0 : 2.0) / (double)n;
+    const unsigned g1 = (unsigned)((n1 + 31) / 32), g2 = (unsigned)((n2 + 31) / 32);
     for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.fs_chunk) {
         const unsigned nb = (unsigned)((batch - b0) < (size_t)p.fs_chunk ? (batch - b0) : (size_t)p.fs_chunk);
         const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
         float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
         // x[n1][n2] -> A[n2][n1]
-        fft_transpose_kernel<false><<<dim3(n2 / 32, n1 / 32, nb), 256, 0, st>>>(src, s0, n1, n2, 0.0);
+        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(src, s0, n1, n2, 0.0);
         YG_LAUNCH_CHECK();
         YG_TRY(launch_fft_batch(f1, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n2, st));
         // B[n2][k1] -> C[k1][n2] with W_n^{n2 k1}
-        fft_transpose_kernel<true><<<dim3(n1 / 32, n2 / 32, nb), 256, 0, st>>>(s1, s0, n2, n1, tw_step);
+        fft_transpose_kernel<true><<<dim3(g1, g2, nb), 256, 0, st>>>(s1, s0, n2, n1, tw_step);
         YG_LAUNCH_CHECK();
         YG_TRY(launch_fft_batch(f2, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n1, st));
         // D[k1][k2] -> X[k2][k1]
-        fft_transpose_kernel<false><<<dim3(n2 / 32, n1 / 32, nb), 256, 0, st>>>(s1, dst, n1, n2, 0.0);
+        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(s1, dst, n1, n2, 0.0);
         YG_LAUNCH_CHECK();
     }
     return YAGI_OK;

@@ -103,9 +103,9 @@ struct FftPlanDev {
     cf32 *bs_scratch = nullptr;      // 2 * bs_chunk * m points
     int bs_chunk = 0;                // transforms per pass through the scratch
     const FftPlanDev *bs_fwd = nullptr, *bs_bwd = nullptr;   // host pointers: the m-point plans (own resources when m > 8192)
-    // four-step form for powers of two above 8192: n = n1 * n2, column transforms, twiddle, row transforms
+    // four-step form above 8192 points: n = n1 * n2 (both <= 8192), column transforms, twiddle, row transforms
     int fs_n1 = 0, fs_n2 = 0;        // 0 = not used
-    const cf32 *fs_tw1 = nullptr, *fs_tw2 = nullptr;          // W_n1, W_n2 tables (sign per direction)
+    const FftPlanDev *fs_p1 = nullptr, *fs_p2 = nullptr;      // host pointers: the n1- and n2-point plans
     cf32 *fs_scratch = nullptr;      // 2 * fs_chunk * n points
     int fs_chunk = 0;
 };
