@@ -396,8 +396,9 @@ YAGI_SPGRAM_API(f, float)
 
 /* ---- the headline stream: FirFilter<Complex32,f32>::execute_block
  * (firfilt.rs:267-278) feeding consecutive nfft-sample frames to Fft::run forward
- * (fft/mod.rs:45-48), fused so the FIR output never touches HBM.  nfft = 4096, 1..2049 taps;
- * filter state carries across calls exactly like the FirFilter object's. */
+ * (fft/mod.rs:45-48).  1..2049 taps; nfft = 4096 is fused so the FIR output never touches HBM, any other nfft the
+ * Fft object supports runs as overlap-save FIR + batched transform (two launches).  Filter state carries across
+ * calls exactly like the FirFilter object's. */
 typedef struct yagi_hip_firfft_crcf_s *yagi_hip_firfft_crcf;
 int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_hip_firfft_crcf *q);
 int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q);

@@ -50,7 +50,10 @@ def test_stream_config(ya):
     with pytest.raises(ya.ConfigError):
         ya.FirFftStream(np.zeros(0, np.float32))
     with pytest.raises(ya.ConfigError):
-        ya.FirFftStream(np.ones(8, np.float32), nfft=1024)
+        ya.FirFftStream(np.ones(8, np.float32), nfft=0)
+    q1 = ya.FirFftStream(np.ones(8, np.float32), nfft=1024)
+    with pytest.raises(ya.ConfigError):
+        q1.set_variant(4)                       # only nfft = 4096 has the fused kernels
     with pytest.raises(ya.ConfigError):
         ya.FirFftStream(np.ones(2050, np.float32))
     q = ya.FirFftStream(np.ones(8, np.float32))
@@ -122,3 +125,18 @@ def test_headline_config_full_block(ya, oracle):
     xs = np.concatenate([tail, dx2.to_numpy(4096)])
     truth = np.fft.fft(oracle.fir_block_f64("crcf", h, xs, scale=0.4)[-4096:])
     assert rel_l2(dy2.to_numpy(4096), truth) <= 1e-5
+
+
+@pytest.mark.parametrize("nfft", [256, 1000, 2048, 8192])
+def test_stream_other_frame_lengths(ya, oracle, nfft):
+    """nfft != 4096: overlap-save FIR + batched transform, same stream semantics"""
+    rng = np.random.default_rng(nfft)
+    h = (rng.standard_normal(129) / 11).astype(np.float32)
+    nframes = 9
+    x = oracle.gen_complex(SEED + 2, nframes * nfft)
+    truth = spectra_truth(oracle, h, 0.4, x, nfft)
+    q = ya.FirFftStream(h, nfft=nfft)
+    q.set_scale(0.4)
+    got = np.concatenate([q.execute(x[: 4 * nfft]), q.execute(x[4 * nfft:])])
+    for f in range(nframes):
+        assert rel_l2(got[f], truth[f]) <= 1e-5, f

@@ -491,6 +491,7 @@ struct FirFft {
     FirFilt<CRCF> fir;
     size_t nfft = 0;
     DevBuf tw;
+    FftPlan plan;              // nfft != 4096: overlap-save FIR, then this plan over the frames
     int variant = 0;
     DevBuf xin, yout;
     DevBuf scratch;            // variant 3: the FIR output stream between the two kernels
@@ -1885,12 +1886,13 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
     CHECK_PTR(q);
     *q = nullptr;
     if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");
-    if (nfft != 4096) return fail(YAGI_ERR_CONFIG, "fused stream supports nfft = 4096 (got %zu)", nfft);
+    if (nfft == 0) return fail(YAGI_ERR_CONFIG, "fft length must be greater than zero");
     auto o = std::make_unique<yagi_hip_firfft_crcf_s>();
     YG_TRY(o->fir.init(h, h_len));
     if (o->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%zu taps, at most 2049)", h_len);
     o->nfft = nfft;
-    YG_TRY(make_twiddles((int)nfft, YAGI_FFT_FORWARD, o->tw));
+    if (nfft == 4096) YG_TRY(make_twiddles((int)nfft, YAGI_FFT_FORWARD, o->tw));
+    else YG_TRY(fft_plan_init(o->plan, nfft, YAGI_FFT_FORWARD));      // any size the Fft object supports
     *q = o.release();
     return YAGI_OK;
 }
@@ -1906,6 +1908,8 @@ int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->f
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     CHECK_Q(q);
     if (variant < 0 || variant > 4) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
+    if (q->nfft != 4096 && variant != 0 && variant != 3)
+        return fail(YAGI_ERR_CONFIG, "nfft = %zu runs as overlap-save FIR + batched FFT (variant 3) only", q->nfft);
     if (variant == 3 && q->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
     if (variant == 4 && q->fir.L > 257) return fail(YAGI_ERR_CONFIG, "frequency-domain variant needs <= 257 taps");
     if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
@@ -1922,6 +1926,16 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     YG_TRY(f.w.flush(f.st));
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
     // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
+    if (q->nfft != 4096) {     // other frame lengths: overlap-save FIR into a scratch stream, then the batched transform
+        YG_TRY(f.prepare_conv());
+        const size_t n = nframes * q->nfft;
+        YG_TRY(q->scratch.ensure(n * sizeof(cf32)));
+        cf32 *ys = q->scratch.as<cf32>();
+        YG_TRY(launch_fir_crcf_fftconv(f.w.dev(), x, 0, n, f.hfreq.as<cf32>(), f.scale, f.L, f.twf.as<cf32>(),
+                                       f.twb.as<cf32>(), ys, n, f.st));
+        YG_TRY(launch_fft_batch(q->plan.d, ys, spectra, nframes, f.st));
+        return f.w.advance(x, n, f.st);
+    }
     const bool use_freq = q->variant == 4 || (q->variant == 0 && f.L <= 257);
     if (use_freq) {
         // frequency-domain form (one kernel, 16 B/sample): FFT{h}.FFT{x_f} + FFT{frame-boundary correction}
