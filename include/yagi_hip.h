@@ -425,6 +425,9 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x_
  *   firpfbch  analyzer: M channels, p taps/branch, prototype h[0 .. p*M); one frame = M input
  *             samples -> M channel outputs: X[M-1-i] = branch_i . window_i ; y = DFT_M(X).
  *             create_kaiser(M, m, as_): h = kaiser(2*M*m+1, 0.5/M, as_), p = 2*m.
+ *   firpfbch  synthesizer: one frame = M channel samples -> M output samples:
+ *             v = IDFT_M(X) (unnormalised); branch i pushes v[i] and y[i] = branch_i . window_i, i.e.
+ *             y[f M + i] = sum_n h[i + n M] v_{f-n}[i].  Own state, reset() clears both.
  *   firpfbch2 analyzer (2x oversampled): M even, branch length 2*m, h[0 .. 2*M*m); one step =
  *             M/2 inputs -> M outputs, alternating half rotation, y = IDFT_M(X)/M.
  *             create_kaiser(M, m, as_): h = kaiser(2*M*m+1, 1/M, as_) * M / sum(h).
@@ -442,6 +445,10 @@ int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi
                                             size_t nframes, yagi_cf32 *y);
 int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x_dev,
                                                 size_t nframes, yagi_cf32 *y_dev);
+int yagi_hip_firpfbch_crcf_synthesizer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x,
+                                               size_t nframes, yagi_cf32 *y);
+int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x_dev,
+                                                   size_t nframes, yagi_cf32 *y_dev);
 
 typedef struct yagi_hip_firpfbch2_crcf_s *yagi_hip_firpfbch2_crcf;
 int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q);

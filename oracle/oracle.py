@@ -529,6 +529,7 @@ class FirPfbCh:
         self.L, self.M, self.p = lib(), M, p
         h = _as(h, np.float32)
         assert len(h) >= M * p
+        self._taps = h.copy()
         self.h = self.L.yo_firpfbch_create(M, p, _p(h))
 
     def __del__(self):
@@ -542,6 +543,26 @@ class FirPfbCh:
         y = np.empty(nf * self.M, np.complex64)
         self.L.yo_firpfbch_analyzer_execute(self.h, _p(x), nf, _p(y))
         return y.reshape(nf, self.M)
+
+    def synthesizer_execute(self, X):
+        """liquid-dsp firpfbch_crcf_synthesizer_execute, frame by frame (PARITY UNPINNED): inverse DFT of the M channel
+        samples (unnormalised), branch i pushes v[i] into its window and y[i] = sum_n h[i + n M] * window_i[newest - n].
+        Sequential f32 accumulation in tap order, like the dot products of the reference's FirPfbFilter."""
+        M, p = self.M, self.p
+        X = _as(X, np.complex64).reshape(-1, M)
+        if not hasattr(self, "_syn_win"):
+            self._syn_win = np.zeros((p, M), np.complex64)          # row 0 = newest inverse transform
+            self._syn_h = np.asarray(self._taps, np.float32)[: M * p].reshape(p, M)   # [n][i] = h[i + n M]
+        y = np.empty(X.shape, np.complex64)
+        for f in range(X.shape[0]):
+            v = (np.fft.ifft(X[f].astype(np.complex128)) * M).astype(np.complex64)
+            self._syn_win = np.roll(self._syn_win, 1, axis=0)
+            self._syn_win[0] = v
+            acc = np.zeros(M, np.complex64)
+            for n in range(p):
+                acc = (acc + self._syn_h[n] * self._syn_win[n]).astype(np.complex64)
+            y[f] = acc
+        return y.reshape(-1)
 
 
 class FirPfbCh2:

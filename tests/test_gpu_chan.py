@@ -267,3 +267,50 @@ def test_config_c5_firpfbch2_256ch_full_size(ya, oracle):
     for s in (0, 513, ns - 1):
         full = dy.to_numpy(M, offset=s * M)
         assert rel_l2(shard.to_numpy(M // R, offset=s * (M // R)), full[r::R]) <= 3e-6, s
+
+
+@pytest.mark.parametrize("M,m,nfr", [(4, 2, 50), (8, 4, 333), (64, 8, 200), (6, 3, 77), (10, 2, 100), (256, 4, 65), (1, 3, 20),
+                                     (512, 2, 40), (48, 4, 90)])
+def test_firpfbch_synthesizer_vs_oracle(ya, oracle, M, m, nfr):
+    """synthesizer (PARITY UNPINNED like the analyzer): frames of channel samples -> time samples, against
+    the frame-by-frame restatement; state carried across calls; its state is independent of the analyzer's"""
+    p = 2 * m
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+    X = oracle.gen_complex(SEED + 6, nfr * M)
+    want = oracle.FirPfbCh(M, p, h).synthesizer_execute(X)
+    q = ya.FirPfbCh(M, p, h)
+    k = nfr // 3
+    q.analyzer_execute(X[: 2 * M])                       # must not disturb the synthesizer's window
+    got = np.concatenate([q.synthesizer_execute(X[: k * M]), q.synthesizer_execute(X[k * M:(k + 1) * M]),
+                          q.synthesizer_execute(X[(k + 1) * M:])])
+    assert rel_l2(got, want) <= 3e-6
+    q.reset()
+    assert rel_l2(q.synthesizer_execute(X[: 3 * M]), want[: 3 * M]) <= 3e-6
+
+
+def test_firpfbch_synthesizer_properties(ya, oracle):
+    """an impulse in channel 0 plays out the prototype (the bank is an M-fold interpolator for channel 0); a constant in
+    channel k alone gives a tone at k/M; linearity"""
+    M, m = 16, 4
+    p = 2 * m
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+    q = ya.FirPfbCh(M, p, h)
+    X = np.zeros((p + 2, M), np.complex64)
+    X[0, 0] = 1.0
+    y = q.synthesizer_execute(X)
+    assert np.allclose(y[: M * p], h[: M * p], atol=1e-6) and np.allclose(y[M * p:], 0, atol=1e-7)
+    for k in (1, 5, 15):
+        q.reset()
+        X = np.zeros((40, M), np.complex64)
+        X[:, k] = 1.0
+        y = q.synthesizer_execute(X)[M * p:]               # steady state
+        n = np.arange(M * p, 40 * M)
+        tone = np.exp(2j * np.pi * k * n / M)
+        gain = np.vdot(tone, y) / len(y)
+        assert abs(abs(gain) - abs(np.sum(h[: M * p]) / M)) <= 2e-3 * abs(np.sum(h)) / M + 1e-4
+        assert np.linalg.norm(y - gain * tone) <= 0.05 * np.linalg.norm(y)
+    rng = np.random.default_rng(3)
+    A = (rng.standard_normal((30, M)) + 1j * rng.standard_normal((30, M))).astype(np.complex64)
+    B = (rng.standard_normal((30, M)) + 1j * rng.standard_normal((30, M))).astype(np.complex64)
+    qa, qb, qc = (ya.FirPfbCh(M, p, h) for _ in range(3))
+    assert rel_l2(qc.synthesizer_execute(A + 2 * B), qa.synthesizer_execute(A) + 2 * qb.synthesizer_execute(B)) <= 1e-6

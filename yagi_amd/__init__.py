@@ -841,6 +841,19 @@ class FirPfbCh(_Handle):
     def analyzer_execute_dev(self, x_dev, nframes, y_dev):
         _check(lib.yagi_hip_firpfbch_crcf_analyzer_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(y_dev)))
 
+    def synthesizer_execute(self, X):
+        """X: frames of M channel samples ([nframes, M] or flat) -> nframes*M output samples"""
+        X = _arr(X, np.complex64)
+        if X.size % self.M:
+            raise ConfigError("input must hold a whole number of M-channel frames")
+        nf = X.size // self.M
+        y = np.empty(X.size, np.complex64)
+        _check(lib.yagi_hip_firpfbch_crcf_synthesizer_execute(self._h, _ptr(X), nf, _ptr(y)))
+        return y
+
+    def synthesizer_execute_dev(self, x_dev, nframes, y_dev):
+        _check(lib.yagi_hip_firpfbch_crcf_synthesizer_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(y_dev)))
+
 
 class FirPfbCh2(_Handle):
     _prefix = "yagi_hip_firpfbch2_crcf_"

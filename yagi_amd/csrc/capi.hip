@@ -505,6 +505,7 @@ struct PfbCh {
     int M = 0, p = 0;
     DevBuf h, tw;
     DevWindow<cf32> hist;      // (p-1)*M samples (at least 1 kept so the buffers exist)
+    DevWindow<cf32> syn_hist;  // synthesizer: the last (p-1)*M channel samples (its own state, like liquid's separate objects)
     Workspace ws;
 };
 struct PfbCh2 {
@@ -2004,6 +2005,7 @@ int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_f
     YG_TRY(make_twiddles((int)M, YAGI_FFT_FORWARD, o->tw));
     const size_t hl = (p - 1) * M;
     YG_TRY(o->hist.init((int)(hl ? hl : 1), nullptr));
+    YG_TRY(o->syn_hist.init((int)(hl ? hl : 1), nullptr));
     *q = o.release();
     return YAGI_OK;
 }
@@ -2023,7 +2025,11 @@ int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s)
     q->st = to_stream(s);
     return YAGI_OK;
 }
-int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q) { CHECK_Q(q); return q->hist.reset(q->st); }
+int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q) {
+    CHECK_Q(q);
+    YG_TRY(q->hist.reset(q->st));
+    return q->syn_hist.reset(q->st);
+}
 int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
@@ -2044,6 +2050,28 @@ int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi
     YG_TRY(q->ws.y.ensure(bytes));
     YG_TRY(upload(q->ws.x.p, x, bytes, q->st));
     YG_TRY(yagi_hip_firpfbch_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nframes, q->ws.y.as<cf32>()));
+    return download(y, q->ws.y.p, bytes, q->st);
+}
+
+int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    YG_TRY(launch_firpfbch_syn(q->syn_hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st));
+    if (q->p > 1) return q->syn_hist.advance(x, nframes * (size_t)q->M, q->st);
+    return YAGI_OK;
+}
+int yagi_hip_firpfbch_crcf_synthesizer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nframes == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const size_t bytes = nframes * (size_t)q->M * sizeof(cf32);
+    YG_TRY(q->ws.x.ensure(bytes));
+    YG_TRY(q->ws.y.ensure(bytes));
+    YG_TRY(upload(q->ws.x.p, x, bytes, q->st));
+    YG_TRY(yagi_hip_firpfbch_crcf_synthesizer_execute_dev(q, q->ws.x.as<cf32>(), nframes, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, bytes, q->st);
 }
 

@@ -468,6 +468,79 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// firpfbch synthesizer (liquid-dsp firpfbch_crcf_synthesizer_execute semantics; absent from the reference):
+//   v_f[i] = sum_k X_f[k] e^{+j 2 pi i k / M}                       (unnormalised inverse DFT of frame f)
+//   y[f M + i] = sum_{n < p} h[i + n M] v_{f-n}[i]                  (branch i: window push, then dot product)
+// One workgroup = a tile of F output frames: it loads and inverse-transforms frames f0-(p-1) .. f0+F-1 (the first
+// p-1 of them from the previous tile / the history) in LDS and then evaluates the F M branch dot products with
+// the taps read coalesced from L2.  POW2 as in firpfbch_kernel.
+// ---------------------------------------------------------------------------------------------
+template <bool POW2>
+__global__ void __launch_bounds__(256)
+firpfbch_syn_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                    const float *__restrict__ h, int M, int p, const float2 *__restrict__ twM,
+                    FacList fl, Pow2Plan plan, float2 *__restrict__ y, size_t nframes, int F) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *va = reinterpret_cast<float2 *>(smem);              // (F + p - 1) * M
+    float2 *vb = va + (size_t)(F + p - 1) * M;                  // (F + p - 1) * M
+    float2 *twl = vb + (size_t)(F + p - 1) * M;                 // M
+    const int hist_len = (p - 1) * M;
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    const size_t f0 = (size_t)blockIdx.x * F;
+    const int nf = (int)((nframes - f0) < (size_t)F ? (nframes - f0) : (size_t)F);
+    const long long base = (long long)f0 * M - hist_len;
+    const int ntr = nf + p - 1, nspan = ntr * M;
+    const long long x_len = (long long)nframes * M;
+    if (base >= 0 && base + nspan <= x_len) {
+        const float2 *src = x + base;
+        for (int u = threadIdx.x; u < nspan; u += 256) va[u] = src[u];
+    } else {
+        for (int u = threadIdx.x; u < nspan; u += 256) va[u] = load_hist(hist, hist_len, x, base + u, x_len);
+    }
+    __syncthreads();
+    const float2 *res = POW2 ? lds_fft_pow2<+1>(va, vb, M, ntr, plan, twl, 1, true)
+                             : lds_dft_frames(va, vb, M, ntr, fl, twl, 1, true);
+    for (int e = threadIdx.x; e < nf * M; e += 256) {
+        const int f = e / M, i = e - f * M;
+        float2 acc = make_float2(0.f, 0.f);
+        const float2 *vp = res + (f + p - 1) * M + i;            // v_{f0+f}[i]; v_{f0+f-n}[i] is n*M before it
+        for (int n = 0; n < p; ++n) {
+            const float hv = h[i + n * M];
+            const float2 sv = vp[-n * M];
+            acc.x = fmaf(sv.x, hv, acc.x);
+            acc.y = fmaf(sv.y, hv, acc.y);
+        }
+        y[f0 * M + e] = acc;
+    }
+}
+
+int launch_firpfbch_syn(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
+                        const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
+    if (nframes == 0) return YAGI_OK;
+    int F = 4096 / M;
+    if (F < 1) F = 1;
+    auto need = [&](int f) { return (2 * (size_t)(f + p - 1) * M + (size_t)M) * sizeof(float2); };
+    const size_t budget = 78 * 1024;
+    while (F > 1 && need(F) > budget) F /= 2;
+    if (need(F) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch synthesizer: M*p too large for LDS (%d x %d)", M, p);
+    const bool pow2 = is_pow2(M);
+    const void *fn = pow2 ? reinterpret_cast<const void *>(firpfbch_syn_kernel<true>)
+                          : reinterpret_cast<const void *>(firpfbch_syn_kernel<false>);
+    if (need(F) > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t tiles = (nframes + F - 1) / F;
+    if (tiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (pow2)
+        firpfbch_syn_kernel<true><<<(unsigned)tiles, 256, need(F), st>>>(fh, fx, h, M, p, ftw, FacList{0, {0}}, make_pow2_plan(M), fy, nframes, F);
+    else
+        firpfbch_syn_kernel<false><<<(unsigned)tiles, 256, need(F), st>>>(fh, fx, h, M, p, ftw, factorize_small(M), Pow2Plan{0, {0}}, fy, nframes, F);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // firpfbch2 analyzer (optionally one rank's sub-band shard)
 // ---------------------------------------------------------------------------------------------
 template <bool POW2>
