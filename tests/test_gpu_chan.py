@@ -270,7 +270,7 @@ def test_config_c5_firpfbch2_256ch_full_size(ya, oracle):
 
 
 @pytest.mark.parametrize("M,m,nfr", [(4, 2, 50), (8, 4, 333), (64, 8, 200), (6, 3, 77), (10, 2, 100), (256, 4, 65), (1, 3, 20),
-                                     (512, 2, 40), (48, 4, 90)])
+                                     (512, 2, 40), (48, 4, 90), (64, 8, 5000), (16, 2, 9001), (256, 2, 40000), (32, 4, 777)])
 def test_firpfbch_synthesizer_vs_oracle(ya, oracle, M, m, nfr):
     """synthesizer (PARITY UNPINNED like the analyzer): frames of channel samples -> time samples, against
     the frame-by-frame restatement; state carried across calls; its state is independent of the analyzer's"""

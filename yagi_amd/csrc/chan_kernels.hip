@@ -514,9 +514,122 @@ firpfbch_syn_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     }
 }
 
+// Column-sliding synthesizer (M in {8..256}, p in {4,8,16}): the mirror image of firpfbch_col_kernel.  Per half tile of
+// 8 frames: coalesced loads of the channel frames -> LDS -> static inverse radix passes -> every lane (one branch
+// column i) takes its 8 values back, pushes them through its p-deep register ring and stores y[f M + i] coalesced.
+// A run starts with W = 8 (p <= 8) or 16 warm-up frames (the p-1 frames before it, inverse-transformed again)
+// whose outputs are not stored.
+template <int P, int LGM>
+__global__ void __launch_bounds__(256)
+firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                        const float *__restrict__ h, const float2 *__restrict__ twM,
+                        float2 *__restrict__ y, size_t nframes, int run) {
+    constexpr int M = 1 << LGM, lgM = LGM;
+    constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int G = 256 / M;
+    constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;
+    constexpr int pitch = col_pitch(M, nq);
+    constexpr int W = P <= 8 ? 8 : 16;                           // warm-up frames per run (>= P - 1)
+    float2 *va = reinterpret_cast<float2 *>(smem);
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;
+    const int g = threadIdx.x >> lgM, c = threadIdx.x & (M - 1);
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    float hc[P];
+#pragma unroll
+    for (int n = 0; n < P; ++n) hc[n] = h[c + n * M];
+    const int hist_len = (P - 1) * M;
+    const long long x_len = (long long)nframes * M;
+    const long long f_begin = ((long long)blockIdx.x * G + g) * run;
+    const long long left = (long long)nframes - f_begin;
+    const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
+    float2 w[P];
+#pragma unroll
+    for (int n = 0; n < P; ++n) w[n] = make_float2(0.f, 0.f);
+    auto half_tile = [&](int t, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
+        // channel frames t .. t+7 of this group (negative: the frames before the run; beyond the end: zeros)
+#pragma unroll
+        for (int j = 0; j < kColHalf; ++j) {
+            const long long f = f_begin + t + j;
+            va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, f * M + c, x_len)
+                                                                 : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        const float2 *res = vb;
+        if constexpr (R1 > 1) {
+            stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+            __syncthreads();
+            res = va;
+        }
+#pragma unroll
+        for (int j = 0; j < kColHalf; ++j) {
+            w[(S0 + j) % P] = res[(g * kColHalf + j) * pitch + c];
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < P; ++n) {
+                const float2 sv = w[(S0 + j - n + 4 * P) % P];
+                acc.x = fmaf(sv.x, hc[n], acc.x);
+                acc.y = fmaf(sv.y, hc[n], acc.y);
+            }
+            if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc;
+        }
+        __syncthreads();                             // the next half tile overwrites va / vb
+    };
+    if constexpr (P <= 8) {
+        for (int t0 = -W; t0 < run; t0 += kColHalf) half_tile(t0, std::integral_constant<int, 0>{});
+    } else {
+        for (int t0 = -W; t0 < run; t0 += kColTile) {
+            half_tile(t0, std::integral_constant<int, 0>{});
+            half_tile(t0 + kColHalf, std::integral_constant<int, kColHalf>{});
+        }
+    }
+}
+
+template <int P, int LGM>
+static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
+                                   cf32 *y, size_t nframes, hipStream_t st) {
+    constexpr int M = 1 << LGM;
+    const int G = 256 / M;
+    size_t run = nframes / ((size_t)YG_COL_WGS * G);
+    run = run / kColTile * kColTile;
+    if (run < (size_t)kColTile) run = kColTile;
+    if (run > 256) run = 256;
+    const size_t ngroups = (nframes + run - 1) / run;
+    const size_t nblk = (ngroups + G - 1) / G;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
+    firpfbch_syn_col_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
+                                                                     reinterpret_cast<const float2 *>(x), h,
+                                                                     reinterpret_cast<const float2 *>(twM),
+                                                                     reinterpret_cast<float2 *>(y), nframes, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 int launch_firpfbch_syn(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
                         const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
     if (nframes == 0) return YAGI_OK;
+    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && nframes >= 64) {
+#define YG_SYN_CASE(PP)                                                                              \
+    case PP:                                                                                         \
+        return M == 8 ? launch_firpfbch_syn_col<PP, 3>(hist, x, h, twM, y, nframes, st)              \
+             : M == 16 ? launch_firpfbch_syn_col<PP, 4>(hist, x, h, twM, y, nframes, st)             \
+             : M == 32 ? launch_firpfbch_syn_col<PP, 5>(hist, x, h, twM, y, nframes, st)             \
+             : M == 64 ? launch_firpfbch_syn_col<PP, 6>(hist, x, h, twM, y, nframes, st)             \
+             : M == 128 ? launch_firpfbch_syn_col<PP, 7>(hist, x, h, twM, y, nframes, st)            \
+                        : launch_firpfbch_syn_col<PP, 8>(hist, x, h, twM, y, nframes, st);
+        switch (p) {
+            YG_SYN_CASE(4)
+            YG_SYN_CASE(8)
+            YG_SYN_CASE(16)
+            default: break;
+        }
+#undef YG_SYN_CASE
+    }
     int F = 4096 / M;
     if (F < 1) F = 1;
     auto need = [&](int f) { return (2 * (size_t)(f + p - 1) * M + (size_t)M) * sizeof(float2); };
