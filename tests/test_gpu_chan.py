@@ -314,3 +314,22 @@ def test_firpfbch_synthesizer_properties(ya, oracle):
     B = (rng.standard_normal((30, M)) + 1j * rng.standard_normal((30, M))).astype(np.complex64)
     qa, qb, qc = (ya.FirPfbCh(M, p, h) for _ in range(3))
     assert rel_l2(qc.synthesizer_execute(A + 2 * B), qa.synthesizer_execute(A) + 2 * qb.synthesizer_execute(B)) <= 1e-6
+
+
+@pytest.mark.parametrize("M,p", [(16, 4), (64, 16), (256, 8), (512, 4), (12, 3)])
+def test_firpfbch_analysis_synthesis_round_trip(ya, M, p):
+    """size-independent property: with the block prototype h = [1]*M (+ zero taps so that the p-tap kernels run) the
+    analyzer is a per-frame DFT and the synthesizer its inverse, so synthesizer(analyzer(x)) = M x over the whole
+    stream -- 2^22 device-resident samples, every sample compared"""
+    h = np.zeros(M * p, np.float32)
+    h[:M] = 1.0
+    n = (1 << 22) // M * M
+    dx = ya.gen_complex_dev(SEED + 7, n)
+    dX = ya.DeviceArray(n, np.complex64)
+    dy = ya.DeviceArray(n, np.complex64)
+    q = ya.FirPfbCh(M, p, h)
+    q.analyzer_execute_dev(dx, n // M, dX)
+    q.synthesizer_execute_dev(dX, n // M, dy)
+    ya.synchronize()
+    x, y = dx.to_numpy(), dy.to_numpy()
+    assert rel_l2(y, M * x.astype(np.complex128)) <= 2e-6
