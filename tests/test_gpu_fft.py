@@ -158,3 +158,23 @@ def test_fft_size_limits(ya):
         ya.Fft((1 << 24) + 1, ya.Direction.Forward)         # not a power of two and 2n-1 > 2^24
     with pytest.raises(ya.ConfigError):
         ya.Fft(1 << 25, ya.Direction.Forward)
+
+
+@pytest.mark.parametrize("n,total", [(4096, 1 << 26), (1024, 1 << 24), (8192, 1 << 24), (100, 100 * 50000), (65536, 1 << 24)])
+def test_fft_round_trip_whole_buffer(ya, n, total):
+    """size-independent property at scale: backward(forward(x)) = n x, every point of a large device buffer compared"""
+    batch = total // n
+    dx = ya.gen_complex_dev(SEED + 3, batch * n)
+    dX = ya.DeviceArray(batch * n, np.complex64)
+    dy = ya.DeviceArray(batch * n, np.complex64)
+    ya.Fft(n, ya.Direction.Forward).run_batch_dev(dx, dX, batch)
+    ya.Fft(n, ya.Direction.Backward).run_batch_dev(dX, dy, batch)
+    ya.synchronize()
+    x, y = dx.to_numpy(), dy.to_numpy()
+    err = np.linalg.norm(y / np.float32(n) - x) / np.linalg.norm(x)
+    assert err <= 2e-6, err
+    # Parseval on the forward spectra: sum |X|^2 = n sum |x|^2
+    X = dX.to_numpy()
+    e_X = np.sum(np.abs(X).astype(np.float64) ** 2)
+    e_x = np.sum(np.abs(x).astype(np.float64) ** 2)
+    assert abs(e_X / (n * e_x) - 1.0) <= 1e-6
