@@ -140,3 +140,38 @@ def test_stream_other_frame_lengths(ya, oracle, nfft):
     got = np.concatenate([q.execute(x[: 4 * nfft]), q.execute(x[4 * nfft:])])
     for f in range(nframes):
         assert rel_l2(got[f], truth[f]) <= 1e-5, f
+
+
+@pytest.mark.parametrize("delay", [0, 1, 100, 255])
+def test_stream_pure_delay_whole_block(ya, delay):
+    """size-independent property at bench size: with h = delta[k - delay] (256 taps) the filtered stream is the input
+    delayed, so every spectrum must equal the transform of the delayed stream's frame -- all 4096 frames of a 2^24
+    sample block compared, for the default (frequency-domain: this exercises the frame-boundary correction on every
+    frame), overlap-save and direct-form variants, and across a second call (carried state)"""
+    L, nfft, nframes, extra = 256, 4096, 4096, 8
+    h = np.zeros(L, np.float32)
+    h[delay] = 1.0
+    n = nframes * nfft
+    ntot = n + extra * nfft
+    dx = ya.gen_complex_dev(SEED + 8, ntot)
+    src = dx.to_numpy()
+    # reference spectra: batched FFT of the delayed stream (zeros before the start)
+    dd = ya.DeviceArray.from_numpy(np.concatenate([np.zeros(delay, np.complex64), src[: ntot - delay]]))
+    dref = ya.DeviceArray(ntot, np.complex64)
+    ya.Fft(nfft, ya.Direction.Forward).run_batch_dev(dd, dref, nframes + extra)
+    ya.synchronize()
+    ref = dref.to_numpy()
+    dtail = ya.DeviceArray.from_numpy(src[n:])
+    for variant in (0, 3, 2):
+        q = ya.FirFftStream(h)
+        q.set_variant(variant)
+        dy = ya.DeviceArray(n, np.complex64)
+        q.execute_dev(dx, nframes, dy)
+        ya.synchronize()
+        got = dy.to_numpy()
+        assert rel_l2(got, ref[:n]) <= 2e-6, variant
+        assert np.max(np.abs(got - ref[:n])) <= 2e-3, variant      # |X| ~ 64: a few ulp of the spectrum magnitude
+        q.execute_dev(dtail, extra, dy)                            # second call continues the stream
+        ya.synchronize()
+        assert rel_l2(dy.to_numpy(extra * nfft), ref[n:]) <= 2e-6, variant
+        dy.free()
