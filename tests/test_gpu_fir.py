@@ -384,3 +384,37 @@ def test_firpfb_block_all_select_vs_oracle(ya, oracle, kind, nf, hlen, n):
         q.execute_select(np.full(4, nf, np.uint32), x[:4])
     with pytest.raises(ya.ConfigError):
         q.execute_block(nf, x[:4])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_pure_delay_whole_buffer_exact(ya, kind):
+    """size-independent property, bit-exact: h = delta[k - d] makes the direct-form kernels copy the input delayed by d
+    (firfilt: every kernel choice; firdecim: every M-th sample), checked on every output of 2^22-sample device buffers;
+    the overlap-save kernel reproduces it to f32 rounding"""
+    L, d, n = 129, 77, 1 << 22
+    h = np.zeros(L, np.complex64 if kind == "cccf" else np.float32)
+    h[d] = 1.0
+    dx = ya.gen_real_dev(SEED + 9, n) if kind == "rrrf" else ya.gen_complex_dev(SEED + 9, n)
+    x = dx.to_numpy()
+    delayed = np.concatenate([np.zeros(d, x.dtype), x[: n - d]])
+    for choice in ((0, 1, 2, 3, 4) if kind == "crcf" else (0, 1, 4)):
+        q = ya.FirFilter(kind, h)
+        q.set_kernel(choice)
+        dy = ya.DeviceArray(n, x.dtype)
+        q.execute_block_dev(dx, n, dy)
+        ya.synchronize()
+        y = dy.to_numpy()
+        if choice == 4:
+            assert rel_l2(y, delayed) <= 1e-6
+        else:
+            assert np.array_equal(y, delayed), choice
+        dy.free()
+    for M in (2, 4, 5):
+        q = ya.FirDecimationFilter(kind, M, h)
+        dy = ya.DeviceArray(n // M, x.dtype)
+        q.execute_block_dev(dx, n // M, dy)
+        ya.synchronize()
+        # firdecim.rs:179-205: the M samples of a frame are pushed, the output is taken after the FIRST one
+        want = np.concatenate([np.zeros(d, x.dtype), x])[np.arange(n // M) * M]
+        assert np.array_equal(dy.to_numpy(), want), M
+        dy.free()
