@@ -195,22 +195,45 @@ __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *
     fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
 }
 
-// Transform of a sequence that is zero from sample 256 on: lane t holds x[t] in x0 (x[256a + t] = 0 for
-// a >= 1), so the first 16-point butterfly degenerates to Z_c[t] = W4096^{tc} x[t] -- pass 1 is 15
-// twiddle products instead of a butterfly.  Output layout as fft4096_passes_to_regs.
-template <int SIGN, bool TWP = true>
-__device__ __forceinline__ void fft4096_head256_to_regs(float2 x0, float2 (&v)[16], float2 *__restrict__ lds,
-                                                        const float2 *__restrict__ tw) {
+// Transform of a sequence that is zero from sample 256 on.  The first 16-point butterfly degenerates to
+// Z_c[b] = W4096^{bc} x[b], so pass 1 and its whole exchange are skipped: the 256 samples xs[0..256) sit in LDS
+// OUTSIDE the exchange buffer `lds` (written by the caller, a barrier ago), and the pass-2 lane (c, b') rebuilds
+// its inputs
+//     Z_c[16a + b'] = x[16a + b'] (W^{16c})^a W^{b'c}
+// from the power table of W^{16c} (4 exact loads + products); the factor W^{b'c}, common to all 16 inputs, is
+// applied to the butterfly's outputs together with the pass-2 twiddle.  Output layout as fft4096_passes_to_regs.
+// One barrier (after the exchange-2 writes); `lds` must be free on entry and is NOT released by a trailing barrier.
+template <int SIGN>
+__device__ __forceinline__ void fft4096_head256_to_regs(const float2 *__restrict__ xs, float2 (&v)[16],
+                                                        float2 *__restrict__ lds, const float2 *__restrict__ tw) {
     const unsigned t = threadIdx.x;
+    const unsigned c = t >> 4, bp = t & 15;
     {
-        float2 w[16];
-        if (TWP) twiddle_powers(w, tw, t, 4095u);
-        lds[t] = x0;
+        float2 wa[16];
+        twiddle_powers(wa, tw, 16 * c, 4095u);                   // W^{16 c a}, a = 1..15: 16 c a <= 3600
+        v[0] = xs[bp];
 #pragma unroll
-        for (int c = 1; c < 16; ++c) lds[c * kEx1Stride + t] = cmul(x0, TWP ? w[c] : tw[(unsigned)(t * c)]);
+        for (int a = 1; a < 16; ++a) v[a] = cmul(xs[16 * a + bp], wa[a]);
+    }
+    dft16<SIGN>(v);
+    {
+        float2 wt[16];
+        twiddle_powers(wt, tw, 16 * bp, 4095u);                  // pass-2 twiddles W^{16 b' c'}
+        const float2 wbc = tw[bp * c];                            // W^{b' c}
+#pragma unroll
+        for (int cp = 0; cp < 16; ++cp) {
+            float2 u = cmul(v[dft16_pos(cp)], wbc);
+            if (cp) u = cmul(u, wt[cp]);
+            lds[bp * kEx2Stride + cp * 16 + c] = u;
+        }
     }
     __syncthreads();
-    fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
+    float2 w[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) w[b] = lds[b * kEx2Stride + t];
+    dft16<SIGN>(w);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) v[d] = w[dft16_pos(d)];
 }
 
 }  // namespace yagi

@@ -567,7 +567,8 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
                              const float2 *__restrict__ hs, const float *__restrict__ gcorr, float scale, int L,
                              const float2 *__restrict__ tw, float2 *__restrict__ out,
                              float2 *__restrict__ win_next, unsigned nframes) {
-    __shared__ __attribute__((aligned(16))) float2 lds[kFft4096LdsFloat2];
+    __shared__ __attribute__((aligned(16))) float2 lds[kFft4096LdsFloat2 + 256];   // + the 256 correction samples
+    float2 *cvs = lds + kFft4096LdsFloat2;
 #ifdef YG_ABL_SAMEFRAME
     const unsigned t = threadIdx.x, f = blockIdx.x & 15; // ablation: everything from / to L2
 #else
@@ -644,11 +645,12 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
         cp[1] = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
     }
     __syncthreads();
-    float2 cv;
     {
+        // c_f[t] goes to LDS beside the exchange buffer; the barriers of the frame transform below make it visible
+        // to the pass-2 lanes of the correction transform
         const float2 *cp = lds + kDLen + pidx(t);
         const float2 p0 = cp[0], p1 = cp[kPartStride], p2 = cp[2 * kPartStride], p3 = cp[3 * kPartStride];
-        cv = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) * scale, ((p0.y + p1.y) + (p2.y + p3.y)) * scale);
+        cvs[t] = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) * scale, ((p0.y + p1.y) + (p2.y + p3.y)) * scale);
     }
     __syncthreads();
     fft4096_passes_to_regs<-1, true>(v, lds, tw);
@@ -660,9 +662,9 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     float2 u[16];
 #ifdef YG_ABL_NOHEAD
 #pragma unroll
-    for (unsigned d = 0; d < 16; ++d) u[d] = cv;
+    for (unsigned d = 0; d < 16; ++d) u[d] = cvs[t];
 #else
-    fft4096_head256_to_regs<-1, true>(cv, u, lds, tw);
+    fft4096_head256_to_regs<-1>(cvs, u, lds, tw);
 #endif
     float2 *o = out + (size_t)f * 4096;
 #pragma unroll
