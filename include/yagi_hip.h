@@ -428,6 +428,10 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x_
  *   firpfbch  synthesizer: one frame = M channel samples -> M output samples:
  *             v = IDFT_M(X) (unnormalised); branch i pushes v[i] and y[i] = branch_i . window_i, i.e.
  *             y[f M + i] = sum_n h[i + n M] v_{f-n}[i].  Own state, reset() clears both.
+ *   firpfbch2 synthesizer: one step = M channel samples -> M/2 outputs; v_s = IDFT_M(X_s)/2, f = step parity, b = i + f M/2:
+ *             y[s M/2 + i] = sum_n h[i + n M] v_{s-2n}[b] + sum_n h[i + M/2 + n M] v_{s-1-2n}[b].  With the analyzer's
+ *             create_kaiser (cutoff 1/M) and create_kaiser_synthesizer (cutoff 0.5/M) prototypes the round trip
+ *             reproduces the input delayed by 2 M m - M/2 + 1 samples (-60 dB at m = 3).
  *   firpfbch2 analyzer (2x oversampled): M even, branch length 2*m, h[0 .. 2*M*m); one step =
  *             M/2 inputs -> M outputs, alternating half rotation, y = IDFT_M(X)/M.
  *             create_kaiser(M, m, as_): h = kaiser(2*M*m+1, 1/M, as_) * M / sum(h).
@@ -453,6 +457,9 @@ int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, con
 typedef struct yagi_hip_firpfbch2_crcf_s *yagi_hip_firpfbch2_crcf;
 int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q);
 int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q);
+/* prototype of the matching synthesizer: kaiser(2*M*m+1, 0.5/M, as_) * M / sum(h) */
+int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float as_,
+                                                      yagi_hip_firpfbch2_crcf *q);
 int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q);
 int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s);
 int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q);
@@ -460,6 +467,11 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const ya
                                              size_t nsteps, yagi_cf32 *y);
 int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x_dev,
                                                  size_t nsteps, yagi_cf32 *y_dev);
+/* synthesizer: one step = M channel samples -> M/2 output samples (include note above); own state and step parity */
+int yagi_hip_firpfbch2_crcf_synthesizer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x,
+                                                size_t nsteps, yagi_cf32 *y);
+int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x_dev,
+                                                    size_t nsteps, yagi_cf32 *y_dev);
 int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q,
                                                        const yagi_cf32 *x_dev, size_t nsteps,
                                                        int rank, int nranks, yagi_cf32 *yshard_dev);

@@ -572,6 +572,7 @@ class FirPfbCh2:
         self.L, self.M, self.m = lib(), M, m
         h = _as(h, np.float32)
         assert len(h) >= 2 * M * m
+        self._taps = h.copy()
         self.h = self.L.yo_firpfbch2_create(M, m, _p(h))
         if not self.h:
             raise ValueError("config")
@@ -587,6 +588,36 @@ class FirPfbCh2:
         y = np.empty(ns * self.M, np.complex64)
         self.L.yo_firpfbch2_analyzer_execute(self.h, _p(x), ns, _p(y))
         return y.reshape(ns, self.M)
+
+    def synthesizer_execute(self, X):
+        """liquid-dsp firpfbch2_crcf_execute_synthesizer, step by step (PARITY UNPINNED): inverse DFT of the M channel
+        samples (unnormalised, then / 2 so that analyzer -> synthesizer has unit gain), pushed into window set w1 on
+        even steps and w0 on odd steps; output i < M/2 reads windows b = i (even) or i + M/2 (odd) of both sets, the
+        freshly fed set going to sub-filter i, the other to sub-filter i + M/2.  Pinned by the reconstruction test."""
+        M, m = self.M, self.m
+        M2, p = M // 2, 2 * m
+        X = _as(X, np.complex64).reshape(-1, M)
+        if not hasattr(self, "_syn"):
+            hs = np.asarray(self._taps, np.float32)[: M * p].reshape(p, M)          # hs[n][i] = h[i + n M]
+            self._syn = dict(w0=np.zeros((M, p), np.complex64), w1=np.zeros((M, p), np.complex64), flag=0, hs=hs)
+        st = self._syn
+        out = np.empty((X.shape[0], M2), np.complex64)
+        for s in range(X.shape[0]):
+            v = (np.fft.ifft(X[s].astype(np.complex128)) * (M / 2.0)).astype(np.complex64)
+            buf = st["w1"] if st["flag"] == 0 else st["w0"]
+            buf[:, 1:] = buf[:, :-1].copy()
+            buf[:, 0] = v
+            for i in range(M2):
+                b = i if st["flag"] == 0 else i + M2
+                r0, r1 = st["w0"][b], st["w1"][b]
+                p0, p1 = (r0, r1) if st["flag"] else (r1, r0)
+                acc = np.complex64(0)
+                for n in range(p):                       # f32, fresh-set tap then other-set tap: the device order
+                    acc = np.complex64(acc + st["hs"][n, i] * p0[n])
+                    acc = np.complex64(acc + st["hs"][n, i + M2] * p1[n])
+                out[s, i] = acc
+            st["flag"] = 1 - st["flag"]
+        return out.reshape(-1)
 
 
 class FftFilt:

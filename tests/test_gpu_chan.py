@@ -333,3 +333,40 @@ def test_firpfbch_analysis_synthesis_round_trip(ya, M, p):
     ya.synchronize()
     x, y = dx.to_numpy(), dy.to_numpy()
     assert rel_l2(y, M * x.astype(np.complex128)) <= 2e-6
+
+
+@pytest.mark.parametrize("M,m,ns", [(4, 1, 40), (8, 2, 101), (16, 4, 64), (64, 3, 50), (6, 2, 33), (10, 1, 50), (256, 2, 21)])
+def test_firpfbch2_synthesizer_vs_oracle(ya, oracle, M, m, ns):
+    """firpfbch2 synthesizer (PARITY UNPINNED) against the step-by-step restatement; odd splits carry the
+    step parity and the window across calls; independent of the analyzer's state"""
+    h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+    h = (h * M / h.sum()).astype(np.float32)
+    X = oracle.gen_complex(SEED + 10, ns * M)
+    want = oracle.FirPfbCh2(M, m, h).synthesizer_execute(X)
+    q = ya.FirPfbCh2(M, m, h)
+    q.analyzer_execute(X[: 3 * (M // 2)])               # must not disturb the synthesizer
+    k = ns // 3 | 1                                     # odd: the second call starts on an odd step
+    got = np.concatenate([q.synthesizer_execute(X[: k * M]), q.synthesizer_execute(X[k * M:(k + 1) * M]),
+                          q.synthesizer_execute(X[(k + 1) * M:])])
+    assert got.shape == (ns * M // 2,)
+    assert rel_l2(got, want) <= 3e-6
+    q.reset()
+    assert rel_l2(q.synthesizer_execute(X[: 5 * M]), want[: 5 * M // 2]) <= 3e-6
+
+
+@pytest.mark.parametrize("M,m,tol_db", [(16, 4, -70.0), (64, 3, -55.0), (256, 4, -70.0), (12, 4, -70.0)])
+def test_firpfbch2_perfect_reconstruction(ya, M, m, tol_db):
+    """the property that pins both firpfbch2 conventions: analyzer (prototype cutoff 1/M) followed by the synthesizer
+    (cutoff 0.5/M) reproduces the input delayed by 2 M m - M/2 + 1 samples with unit gain, over 2^20 device samples"""
+    n = (1 << 20) // M * M
+    ns = n // (M // 2)
+    dx = ya.gen_complex_dev(SEED + 11, n)
+    dX = ya.DeviceArray(ns * M, np.complex64)
+    dy = ya.DeviceArray(n, np.complex64)
+    ya.FirPfbCh2.new_kaiser(M, m, 80.0).analyzer_execute_dev(dx, ns, dX)
+    ya.FirPfbCh2.new_kaiser_synthesizer(M, m, 80.0).synthesizer_execute_dev(dX, ns, dy)
+    ya.synchronize()
+    x, y = dx.to_numpy(), dy.to_numpy()
+    d = 2 * M * m - M // 2 + 1
+    err = np.linalg.norm(y[d:] - x[: n - d]) / np.linalg.norm(x[: n - d])
+    assert 20 * np.log10(err) <= tol_db, 20 * np.log10(err)

@@ -874,6 +874,28 @@ class FirPfbCh2(_Handle):
         self._h, self.M, self.m = hd, M, m
         return self
 
+    @classmethod
+    def new_kaiser_synthesizer(cls, M, m, as_):
+        """prototype of the matching synthesizer: kaiser(2Mm+1, 0.5/M, as_) scaled to sum M"""
+        self = object.__new__(cls)
+        hd = C.c_void_p()
+        _check(lib.yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(M, m, as_, C.byref(hd)))
+        self._h, self.M, self.m = hd, M, m
+        return self
+
+    def synthesizer_execute(self, X):
+        """X: steps of M channel samples ([nsteps, M] or flat) -> nsteps*M/2 output samples"""
+        X = _arr(X, np.complex64)
+        if X.size % self.M:
+            raise ConfigError("input must hold a whole number of M-channel steps")
+        ns = X.size // self.M
+        y = np.empty(ns * (self.M // 2), np.complex64)
+        _check(lib.yagi_hip_firpfbch2_crcf_synthesizer_execute(self._h, _ptr(X), ns, _ptr(y)))
+        return y
+
+    def synthesizer_execute_dev(self, x_dev, nsteps, y_dev):
+        _check(lib.yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(self._h, _devptr(x_dev), nsteps, _devptr(y_dev)))
+
     def analyzer_execute(self, x):
         x = _arr(x, np.complex64)
         M2 = self.M // 2

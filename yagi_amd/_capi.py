@@ -220,6 +220,9 @@ _sig("yagi_hip_firpfbch_crcf_synthesizer_execute_dev", vp, vp, sz, vp)
 
 _sig("yagi_hip_firpfbch2_crcf_create", sz, sz, vp, pvp)
 _sig("yagi_hip_firpfbch2_crcf_create_kaiser", sz, sz, f32, pvp)
+_sig("yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer", sz, sz, f32, pvp)
+_sig("yagi_hip_firpfbch2_crcf_synthesizer_execute", vp, vp, sz, vp)
+_sig("yagi_hip_firpfbch2_crcf_synthesizer_execute_dev", vp, vp, sz, vp)
 _sig("yagi_hip_firpfbch2_crcf_destroy", vp)
 _sig("yagi_hip_firpfbch2_crcf_set_stream", vp, vp)
 _sig("yagi_hip_firpfbch2_crcf_reset", vp)

@@ -514,6 +514,8 @@ struct PfbCh2 {
     DevBuf h, tw;
     DevWindow<cf32> hist;      // (2m-1)*M + M/2 samples
     uint64_t step = 0;
+    DevWindow<cf32> syn_hist;  // synthesizer: the last (4m-1)*M channel samples; its own step parity
+    uint64_t syn_step = 0;
     Workspace ws;
 };
 
@@ -2091,6 +2093,7 @@ int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_
     YG_TRY(upload(o->h.p, h, hl * sizeof(float), nullptr));
     YG_TRY(make_twiddles((int)M, YAGI_FFT_FORWARD, o->tw));
     YG_TRY(o->hist.init((int)((2 * m - 1) * M + M / 2), nullptr));
+    YG_TRY(o->syn_hist.init((int)((4 * m - 1) * M), nullptr));
     *q = o.release();
     return YAGI_OK;
 }
@@ -2106,6 +2109,19 @@ int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hi
     for (float &v : hf) v = v * (float)M / hsum;
     return yagi_hip_firpfbch2_crcf_create(M, m, hf.data(), q);
 }
+// prototype of the matching synthesizer: kaiser(2Mm+1, 0.5/M, as), scaled to sum M (analyzer: cutoff 1/M)
+int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) {
+    CHECK_PTR(q);
+    *q = nullptr;
+    if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
+    if (m < 1) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 1");
+    std::vector<float> hf;
+    YG_TRY(design_kaiser(2 * M * m + 1, 0.5f / (float)M, std::fabs(as_), 0.0f, hf));
+    float hsum = 0.0f;
+    for (float v : hf) hsum += v;
+    for (float &v : hf) v = v * (float)M / hsum;
+    return yagi_hip_firpfbch2_crcf_create(M, m, hf.data(), q);
+}
 int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q) { delete q; return YAGI_OK; }
 int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s) {
     CHECK_Q(q);
@@ -2116,7 +2132,31 @@ int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t 
 int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q) {
     CHECK_Q(q);
     q->step = 0;
-    return q->hist.reset(q->st);
+    q->syn_step = 0;
+    YG_TRY(q->hist.reset(q->st));
+    return q->syn_hist.reset(q->st);
+}
+int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    YG_TRY(launch_firpfbch2_syn(q->syn_hist.dev(), q->syn_hist.len, x, q->h.as<float>(), q->M, q->m, q->tw.as<cf32>(),
+                                q->syn_step, y, nsteps, q->st));
+    q->syn_step += nsteps;
+    return q->syn_hist.advance(x, nsteps * (size_t)q->M, q->st);
+}
+int yagi_hip_firpfbch2_crcf_synthesizer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const size_t in_bytes = nsteps * (size_t)q->M * sizeof(cf32), out_bytes = in_bytes / 2;
+    YG_TRY(q->ws.x.ensure(in_bytes));
+    YG_TRY(q->ws.y.ensure(out_bytes));
+    YG_TRY(upload(q->ws.x.p, x, in_bytes, q->st));
+    YG_TRY(yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(q, q->ws.x.as<cf32>(), nsteps, q->ws.y.as<cf32>()));
+    return download(y, q->ws.y.p, out_bytes, q->st);
 }
 int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps,
                                                        int rank, int nranks, yagi_cf32 *y) {

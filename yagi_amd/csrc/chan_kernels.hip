@@ -1103,6 +1103,89 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     return YAGI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// firpfbch2 synthesizer (liquid-dsp firpfbch2_crcf_execute_synthesizer semantics; absent from the reference):
+// one step = M channel samples -> M/2 output samples.  With v_s = IDFT_M(X_s) / 2 (unnormalised inverse DFT; the 1/2
+// gives analyzer -> synthesizer unit gain) and f = parity of the step index, b = i + f M/2:
+//     y[s M/2 + i] = sum_{n < 2m} h[i + n M] v_{s-2n}[b]  +  sum_{n < 2m} h[i + M/2 + n M] v_{s-1-2n}[b],   i < M/2
+// (the two window sets of liquid's implementation are the even- and odd-step inverse transforms).  A workgroup
+// inverse-transforms the S steps of its tile and the 4m - 1 steps before them in LDS, then evaluates the dot products.
+// With the analyzer's prototype kaiser(2Mm+1, 1/M) and the synthesizer's kaiser(2Mm+1, 0.5/M), both scaled to sum M,
+// synthesizer(analyzer(x)) reproduces x delayed by 2Mm - M/2 + 1 samples (-60 dB at m = 3, -87 dB at m = 4, As = 80).
+// ---------------------------------------------------------------------------------------------
+template <bool POW2>
+__global__ void __launch_bounds__(256)
+firpfbch2_syn_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
+                     const float *__restrict__ h, int M, int p /* 2m */, const float2 *__restrict__ twM,
+                     FacList fl, Pow2Plan plan, unsigned long long step0, float2 *__restrict__ y,
+                     size_t nsteps, int S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int M2 = M / 2, back = 2 * p - 1;                     // steps of history one output reaches
+    float2 *va = reinterpret_cast<float2 *>(smem);              // (S + back) * M
+    float2 *vb = va + (size_t)(S + back) * M;
+    float2 *twl = vb + (size_t)(S + back) * M;                  // M
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    const size_t s0 = (size_t)blockIdx.x * S;
+    const int ns = (int)((nsteps - s0) < (size_t)S ? (nsteps - s0) : (size_t)S);
+    const long long base = ((long long)s0 - back) * M;          // first channel sample of the tile's span
+    const int ntr = ns + back, nspan = ntr * M;
+    const long long x_len = (long long)nsteps * M;
+    if (base >= 0 && base + nspan <= x_len) {
+        const float2 *src = x + base;
+        for (int u = threadIdx.x; u < nspan; u += 256) va[u] = src[u];
+    } else {
+        for (int u = threadIdx.x; u < nspan; u += 256) va[u] = load_hist(hist, hist_len, x, base + u, x_len);
+    }
+    __syncthreads();
+    const float2 *res = POW2 ? lds_fft_pow2<+1>(va, vb, M, ntr, plan, twl, 1, true)
+                             : lds_dft_frames(va, vb, M, ntr, fl, twl, 1, true);
+    for (int e = threadIdx.x; e < ns * M2; e += 256) {
+        const int sl = e / M2, i = e - sl * M2;
+        const int f = (int)((step0 + s0 + sl) & 1ull);
+        const int b = i + f * M2;
+        const float2 *vp = res + (size_t)(sl + back) * M + b;   // v_s[b]; v_{s-k}[b] is k*M before it
+        float2 acc = make_float2(0.f, 0.f);
+        for (int n = 0; n < p; ++n) {
+            const float h0 = h[i + n * M], h1 = h[i + M2 + n * M];
+            const float2 a0 = vp[-(2 * n) * M], a1 = vp[-(2 * n + 1) * M];
+            acc.x = fmaf(a0.x, h0, acc.x);
+            acc.y = fmaf(a0.y, h0, acc.y);
+            acc.x = fmaf(a1.x, h1, acc.x);
+            acc.y = fmaf(a1.y, h1, acc.y);
+        }
+        y[s0 * M2 + e] = make_float2(0.5f * acc.x, 0.5f * acc.y);
+    }
+}
+
+int launch_firpfbch2_syn(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
+                         const cf32 *twM, uint64_t step0, cf32 *y, size_t nsteps, hipStream_t st) {
+    if (nsteps == 0) return YAGI_OK;
+    const int p = 2 * m, back = 2 * p - 1;
+    if (hist_len != back * M) return fail(YAGI_ERR_INTERNAL, "firpfbch2 synthesizer: bad history length");
+    int S = 4096 / M;
+    if (S < 1) S = 1;
+    auto need = [&](int s) { return (2 * (size_t)(s + back) * M + (size_t)M) * sizeof(float2); };
+    while (S > 1 && need(S) > 78 * 1024) S /= 2;
+    if (need(S) > 150 * 1024) return fail(YAGI_ERR_CONFIG, "firpfbch2 synthesizer: M*m too large for LDS (%d x %d)", M, m);
+    const bool pow2 = is_pow2(M);
+    const void *fn = pow2 ? reinterpret_cast<const void *>(firpfbch2_syn_kernel<true>)
+                          : reinterpret_cast<const void *>(firpfbch2_syn_kernel<false>);
+    if (need(S) > 64 * 1024) YG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t tiles = (nsteps + S - 1) / S;
+    if (tiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (pow2)
+        firpfbch2_syn_kernel<true><<<(unsigned)tiles, 256, need(S), st>>>(fh, hist_len, fx, h, M, p, ftw, FacList{0, {0}}, make_pow2_plan(M),
+                                                                         (unsigned long long)step0, fy, nsteps, S);
+    else
+        firpfbch2_syn_kernel<false><<<(unsigned)tiles, 256, need(S), st>>>(fh, hist_len, fx, h, M, p, ftw, factorize_small(M), Pow2Plan{0, {0}},
+                                                                          (unsigned long long)step0, fy, nsteps, S);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 // gathered[rank][step][q]  ->  y[step][rank + nranks*q]
 __global__ void __launch_bounds__(256)
 assemble_kernel(const float2 *__restrict__ g, size_t nsteps, int M, int R, float2 *__restrict__ y) {

@@ -148,6 +148,10 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
 // y[f*M + i] = sum_n h[i + n*M] * IDFT_M(frame f-n)[i]
 int launch_firpfbch_syn(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
                         const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st);
+// firpfbch2 synthesizer: x = nsteps steps of M channel samples, hist = the (4m-1)*M channel samples before them,
+// step0 = index of the first step (parity selects the half the outputs come from); y = nsteps*M/2 samples
+int launch_firpfbch2_syn(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
+                         const cf32 *twM, uint64_t step0, cf32 *y, size_t nsteps, hipStream_t st);
 // firpfbch2 analyzer: hist = the 2*m*M - M/2 ... samples preceding x[0]; step0 = index of the
 // first step (parity selects the half rotation).  rank/nranks select sub-bands k = rank + nranks*q.
 int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
