@@ -96,6 +96,9 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
  *   create              new(h)                          :63-79   (h_len == 0 -> CONFIG)
  *   create_kaiser       new_kaiser(n, fc, as_, mu)      :93-97   (design: kaiser.rs:16-51)
  *   create_rect         new_rect(n)                     :149-155 (n in [1,1024])
+ *   create_dc_blocker   new_dc_blocker(m, as_)          :166-170 (design/mod.rs:336-378 fir_design_notch at f0 = 0)
+ *   create_notch        new_notch(m, as_, f0)           :183-186 (real taps: notch pair at +-f0; complex taps: the
+ *                                                       DC blocker mixed to f0, firfilt.rs:25-44)
  *   clone               #[derive(Clone)]                :8       (state continues identically)
  *   set_coefficients    set_coefficients(h) (+reset)    :193-206
  *   reset               reset()                         :209-213
@@ -131,6 +134,8 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
     int yagi_hip_firfilt_##K##_create_kaiser(size_t n, float fc, float as_, float mu,               \
                                              yagi_hip_firfilt_##K *q);                              \
     int yagi_hip_firfilt_##K##_create_rect(size_t n, yagi_hip_firfilt_##K *q);                      \
+    int yagi_hip_firfilt_##K##_create_dc_blocker(size_t m, float as_, yagi_hip_firfilt_##K *q);     \
+    int yagi_hip_firfilt_##K##_create_notch(size_t m, float as_, float f0, yagi_hip_firfilt_##K *q);\
     int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q);                                     \
     int yagi_hip_firfilt_##K##_clone(yagi_hip_firfilt_##K q, yagi_hip_firfilt_##K *out);            \
     int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s);                 \

@@ -94,6 +94,8 @@ def lib():
         L.yo_fft_run_f32.argtypes = [vp, vp, vp]
         L.yo_fir_design_kaiser.restype = C.c_int
         L.yo_fir_design_kaiser.argtypes = [sz, fp, fp, fp, vp]
+        L.yo_fir_design_notch.restype = C.c_int
+        L.yo_fir_design_notch.argtypes = [sz, fp, fp, vp]
         L.yo_besseli0f.restype = fp
         L.yo_besseli0f.argtypes = [fp]
         L.yo_gen_real.argtypes = [C.c_uint64, C.c_uint64, sz, vp]
@@ -508,6 +510,23 @@ def fir_design_kaiser(n, fc, as_, mu=0.0):
     if lib().yo_fir_design_kaiser(n, fc, as_, mu, _p(h)):
         raise ValueError("config")
     return h[:n]
+
+
+def fir_design_notch(m, f0, as_):
+    """design/mod.rs:336-378"""
+    h = np.zeros(2 * max(m, 1) + 1, np.float32)
+    if lib().yo_fir_design_notch(m, f0, as_, _p(h)):
+        raise ValueError("config")
+    return h[: 2 * m + 1]
+
+
+def notch_taps(kind, m, as_, f0):
+    """ComplexNotch (firfilt.rs:17-44): real taps = notch at +-f0; complex taps = DC blocker mixed to f0"""
+    if kind != "cccf":
+        return fir_design_notch(m, f0, as_)
+    h = fir_design_notch(m, 0.0, as_)
+    phi = (np.float32(2.0 * np.pi) * np.float32(f0) * (np.arange(2 * m + 1, dtype=np.float32) - np.float32(m))).astype(np.float32)
+    return (h * (np.cos(phi) + 1j * np.sin(phi))).astype(np.complex64)
 
 
 def gen_real(seed, n, first=0):

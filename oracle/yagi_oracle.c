@@ -491,6 +491,25 @@ int yo_fir_design_kaiser(size_t n, float fc, float as_, float mu, float *h) {
     return YO_OK;
 }
 
+/* fir_design_notch, src/filter/fir/design/mod.rs:336-378 (f32): h = delta[m] - w(i) cos(2 pi f0 (i - m)) / scale */
+int yo_fir_design_notch(size_t m, float f0, float as_, float *h) {
+    if (m < 1 || m > 1000) return YO_ECONFIG;
+    if (f0 < -0.5f || f0 > 0.5f) return YO_ECONFIG;
+    if (as_ <= 0.0f) return YO_ECONFIG;
+    const size_t n = 2 * m + 1;
+    float beta = yo_kaiser_beta(as_);
+    float scale = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float p = -cosf(2.0f * PI_F * f0 * ((float)i - (float)m));
+        float w = yo_window_kaiser(i, n, beta);
+        h[i] = p * w;
+        scale += h[i] * p;
+    }
+    for (size_t i = 0; i < n; i++) h[i] /= scale;
+    h[m] += 1.0f;
+    return YO_OK;
+}
+
 /* ------------------------------------------------------------------------------------
  * taper windows, src/math/windows.rs:76-205 (f32).  type = WindowType discriminant:
  * 1 Hamming 2 Hann 3 BlackmanHarris 4 BlackmanHarris7 5 Kaiser 6 FlatTop 7 Triangular

@@ -418,3 +418,40 @@ def test_pure_delay_whole_buffer_exact(ya, kind):
         want = np.concatenate([np.zeros(d, x.dtype), x])[np.arange(n // M) * M]
         assert np.array_equal(dy.to_numpy(), want), M
         dy.free()
+
+
+def test_firfilt_notch_and_dc_blocker(ya, oracle):
+    """new_notch / new_dc_blocker (firfilt.rs:166-186, design/mod.rs:336-378): coefficients equal the restated design;
+    the reference's acceptance tests: crcf / cccf spectral masks (firfilt.rs:406-433) and the cccf tone-rejection
+    harness (:590-624, tolerance 1e-3) for its six notch frequencies; config errors (:444-446)"""
+    for kind in ("crcf", "cccf", "rrrf"):
+        q = ya.FirFilter.new_notch(kind, 20, 60.0, 0.125)
+        np.testing.assert_allclose(q.get_coefficients(), oracle.notch_taps(kind, 20, 60.0, 0.125), rtol=2e-5, atol=2e-6)
+        d = ya.FirFilter.new_dc_blocker(kind, 7, 40.0)
+        np.testing.assert_allclose(d.get_coefficients(), oracle.fir_design_notch(7, 0.0, 40.0).astype(q.Cdt), rtol=2e-5, atol=2e-6)
+        bads = [lambda: ya.FirFilter.new_dc_blocker(kind, 0, 0.0), lambda: ya.FirFilter.new_notch(kind, 0, 0.0, 0.0)]
+        if kind != "cccf":       # complex taps mix the DC blocker by any f0 (firfilt.rs:34-43): no range check there
+            bads.append(lambda: ya.FirFilter.new_notch(kind, 20, 60.0, 0.7))
+        for bad in bads:
+            with pytest.raises(ya.ConfigError):
+                bad()
+    # spectral masks on the frequency response of the taps (1200-point transform like validate_psd_firfilt)
+    def response_db(h, nfft=1200):
+        H = np.fft.fftshift(np.fft.fft(np.asarray(h, np.complex128), nfft))
+        return np.arange(nfft) / nfft - 0.5, 20 * np.log10(np.abs(H) + 1e-300)
+    f, p = response_db(ya.FirFilter.new_notch("crcf", 20, 60.0, 0.125).get_coefficients())
+    for lo, hi in ((-0.5, -0.20), (-0.06, 0.06), (0.20, 0.5)):
+        assert np.all(np.abs(p[(f >= lo) & (f <= hi)]) <= 0.1)
+    for lo, hi in ((-0.126, -0.124), (0.124, 0.126)):
+        assert np.all(p[(f >= lo) & (f <= hi)] <= -50.0)
+    f, p = response_db(ya.FirFilter.new_notch("cccf", 20, 60.0, 0.125).get_coefficients())
+    assert np.all(np.abs(p[(f <= 0.06)]) <= 0.1) and np.all(np.abs(p[f >= 0.20]) <= 0.1)
+    assert np.all(p[(f >= 0.124) & (f <= 0.126)] <= -50.0)
+    # tone at the notch frequency is removed (through the device filter)
+    for f0 in (0.0, 0.1, 0.456, 0.5, -0.25, -0.389):
+        m, n = 20, 600
+        q = ya.FirFilter.new_notch("cccf", m, 60.0, f0)
+        x = np.exp(2j * np.pi * np.float32(f0) * np.arange(n + 2 * m + 1)).astype(np.complex64)
+        y = q.execute_block(x)[2 * m + 1:]
+        assert abs(np.sqrt(np.mean(np.abs(x[2 * m + 1:]) ** 2)) - 1.0) <= 1e-3
+        assert np.sqrt(np.mean(np.abs(y) ** 2)) <= 1e-3, f0

@@ -264,6 +264,14 @@ class FirFilter(_FirBase):
     def new_rect(cls, kind, n):                              # firfilt.rs:149-155
         return cls._from(kind, "create_rect", n)
 
+    @classmethod
+    def new_dc_blocker(cls, kind, m, as_):                   # firfilt.rs:166-170
+        return cls._from(kind, "create_dc_blocker", m, as_)
+
+    @classmethod
+    def new_notch(cls, kind, m, as_, f0):                    # firfilt.rs:183-186
+        return cls._from(kind, "create_notch", m, as_, f0)
+
     def set_coefficients(self, h):                           # :193-206
         h = _arr(h, self.Cdt)
         _check(self._fn("set_coefficients")(self._h, _ptr(h), h.size))

@@ -75,6 +75,8 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "create", vp, sz, pvp)
     _sig(p + "create_kaiser", sz, f32, f32, f32, pvp)
     _sig(p + "create_rect", sz, pvp)
+    _sig(p + "create_dc_blocker", sz, f32, pvp)
+    _sig(p + "create_notch", sz, f32, f32, pvp)
     _sig(p + "destroy", vp)
     _sig(p + "clone", vp, pvp)
     _sig(p + "set_stream", vp, vp)

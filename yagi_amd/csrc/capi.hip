@@ -19,6 +19,7 @@ namespace yagi {
 
 int design_kaiser(size_t n, float fc, float as_, float mu, std::vector<float> &h);   // host.cpp
 int window_value(int type, size_t i, size_t wlen, float arg, float *out);            // host.cpp
+int design_notch(size_t m, float f0, float as_, std::vector<float> &h);                // host.cpp
 
 static int require_device() {
     static int ok = -1;
@@ -655,6 +656,20 @@ static int firpfb_block_host(FirPfb<K> *q, size_t i, const typename K::T *x, siz
 
 }  // namespace yagi
 
+// ComplexNotch (firfilt.rs:17-44): real coefficients design the notch at f0 directly (a notch pair at +-f0);
+// complex coefficients design the DC blocker and mix it up to f0 (a single notch)
+static int notch_taps(size_t m, float as_, float f0, std::vector<float> &h) { return design_notch(m, f0, as_, h); }
+static int notch_taps(size_t m, float as_, float f0, std::vector<cf32> &h) {
+    std::vector<float> hf;
+    YG_TRY(design_notch(m, 0.0f, as_, hf));
+    h.resize(hf.size());
+    for (size_t i = 0; i < hf.size(); ++i) {
+        const float phi = 2.0f * 3.14159265358979323846f * f0 * ((float)i - (float)m);
+        h[i] = cf32{hf[i] * std::cos(phi), hf[i] * std::sin(phi)};
+    }
+    return YAGI_OK;
+}
+
 #define YAGI_FIR_IMPL(K, KT, T, C)                                                                  \
     struct yagi_hip_firfilt_##K##_s : FirFilt<KT> {};                                               \
     struct yagi_hip_firdecim_##K##_s : FirDecim<KT> {};                                             \
@@ -684,6 +699,22 @@ static int firpfb_block_host(FirPfb<K> *q, size_t i, const typename K::T *x, siz
         *q = nullptr;                                                                               \
         if (n == 0 || n > 1024) return fail(YAGI_ERR_CONFIG, "filter length must be in [1,1024]");  \
         std::vector<C> hc(n, one_of<C>());                                                          \
+        return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_create_notch(size_t m, float as_, float f0, yagi_hip_firfilt_##K *q) { \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        std::vector<C> hc;                                                                          \
+        YG_TRY(notch_taps(m, as_, f0, hc));                                                         \
+        return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_create_dc_blocker(size_t m, float as_, yagi_hip_firfilt_##K *q) {    \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_notch(m, 0.0f, as_, hf));                                                     \
+        std::vector<C> hc(hf.size());                                                               \
+        for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
     }                                                                                               \
     int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q) {                                    \

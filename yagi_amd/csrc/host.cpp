@@ -112,6 +112,29 @@ int design_kaiser(size_t n, float fc, float as_, float mu, std::vector<float> &h
     return YAGI_OK;
 }
 
+// fir_design_notch (design/mod.rs:336-378): 1 - (Kaiser-windowed tone at f0, normalised to unit gain at f0)
+int design_notch(size_t m, float f0, float as_, std::vector<float> &h) {
+    if (m < 1 || m > 1000) return fail(YAGI_ERR_CONFIG, "filter semi-length (%zu) out of range [1,1000]", m);
+    if (f0 < -0.5f || f0 > 0.5f) return fail(YAGI_ERR_CONFIG, "notch frequency (%g) out of range [-0.5,0.5]", (double)f0);
+    if (as_ <= 0.0f) return fail(YAGI_ERR_CONFIG, "stop-band attenuation must be greater than zero");
+    const size_t n = 2 * m + 1;
+    const float beta = kaiser_beta(as_);
+    const float i0_beta = bessel_i0(beta);
+    h.assign(n, 0.0f);
+    float scale = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float p = -std::cos(2.0f * 3.14159265358979323846f * f0 * (static_cast<float>(i) - static_cast<float>(m)));
+        const float tw = static_cast<float>(i) - static_cast<float>(n - 1) / 2.0f;
+        const float r = 2.0f * tw / static_cast<float>(n - 1);
+        const float w = bessel_i0(beta * std::sqrt(1.0f - r * r)) / i0_beta;
+        h[i] = p * w;
+        scale += h[i] * p;
+    }
+    for (size_t i = 0; i < n; ++i) h[i] /= scale;
+    h[m] += 1.0f;
+    return YAGI_OK;
+}
+
 // ---- taper windows for Spgram (math/windows.rs:76-205), single precision like the reference -------
 // type: 1 Hamming, 2 Hann, 3 BlackmanHarris, 4 BlackmanHarris7, 5 Kaiser, 6 FlatTop, 7 Triangular,
 //       8 RcosTaper, 9 Kbd (the reference's WindowType discriminants)
