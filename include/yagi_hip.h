@@ -107,6 +107,8 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
  *   execute_one         execute_one(x)                  :256-259
  *   execute_block       execute_block(x, y)             :267-278 (nx != ny -> CONFIG)
  *   set_scale/get_scale/get_length/get_coefficients      :285-314
+ *   freqresponse        freqresponse(fc)                :325-328 (design/mod.rs:666-675; host arithmetic on the taps)
+ *   groupdelay          groupdelay(fc)                  :339-342 (design/mod.rs:687-704)
  *   y[i] = scale * sum_{k<L} h[k] * x[i-k], history zero at start.
  *
  * firdecim = FirDecimationFilter<T,C>   src/filter/fir/firdecim.rs
@@ -153,6 +155,8 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
     int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *scale);                         \
     int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *h_len);                   \
     int yagi_hip_firfilt_##K##_get_coefficients(yagi_hip_firfilt_##K q, C *h, size_t h_len);        \
+    int yagi_hip_firfilt_##K##_freqresponse(yagi_hip_firfilt_##K q, float fc, yagi_cf32 *H);        \
+    int yagi_hip_firfilt_##K##_groupdelay(yagi_hip_firfilt_##K q, float fc, float *delay);          \
                                                                                                     \
     typedef struct yagi_hip_firdecim_##K##_s *yagi_hip_firdecim_##K;                                \
     int yagi_hip_firdecim_##K##_create(size_t M, const C *h, size_t h_len,                          \
@@ -166,6 +170,7 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
     int yagi_hip_firdecim_##K##_get_decim_rate(yagi_hip_firdecim_##K q, size_t *M);                 \
     int yagi_hip_firdecim_##K##_set_scale(yagi_hip_firdecim_##K q, C scale);                        \
     int yagi_hip_firdecim_##K##_get_scale(yagi_hip_firdecim_##K q, C *scale);                       \
+    int yagi_hip_firdecim_##K##_freqresp(yagi_hip_firdecim_##K q, float fc, yagi_cf32 *H);          \
     int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y);      \
     int yagi_hip_firdecim_##K##_execute_block(yagi_hip_firdecim_##K q, const T *x, size_t nx,       \
                                               size_t n, T *y);                                      \

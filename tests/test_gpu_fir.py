@@ -455,3 +455,28 @@ def test_firfilt_notch_and_dc_blocker(ya, oracle):
         y = q.execute_block(x)[2 * m + 1:]
         assert abs(np.sqrt(np.mean(np.abs(x[2 * m + 1:]) ** 2)) - 1.0) <= 1e-3
         assert np.sqrt(np.mean(np.abs(y) ** 2)) <= 1e-3, f0
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_freqresponse_and_groupdelay(ya, kind):
+    """freqresponse (firfilt.rs:325-328, design/mod.rs:666-675), groupdelay (:339-342, design/mod.rs:687-704) and
+    FirDecimationFilter::freqresp (firdecim.rs:164-168) against their definitions in f64"""
+    rng = np.random.default_rng(12)
+    h = rand_taps(rng, kind, 33)
+    scale = (0.5 - 0.25j) if kind == "cccf" else 0.5
+    q = ya.FirFilter(kind, h)
+    q.set_scale(scale)
+    d = ya.FirDecimationFilter(kind, 3, h)
+    d.set_scale(scale)
+    i = np.arange(33)
+    for fc in (0.0, 0.1, -0.31, 0.5):
+        want = np.sum(h.astype(np.complex128) * np.exp(-2j * np.pi * fc * i)) * scale
+        assert abs(q.freqresponse(fc) - want) <= 1e-5 * (1 + abs(want))
+        assert abs(d.freqresp(fc) - want) <= 1e-5 * (1 + abs(want))
+        e = np.exp(2j * np.pi * fc * i)
+        gd = (np.sum(h.real * e * i) / np.sum(h.real * e)).real
+        assert abs(q.groupdelay(fc) - gd) <= 1e-3 * (1 + abs(gd))
+    sym = ya.FirFilter.new_kaiser(kind, 41, 0.2, 60.0, 0.0)          # linear phase: delay (n-1)/2 everywhere in band
+    assert abs(sym.groupdelay(0.05) - 20.0) <= 1e-3
+    with pytest.raises(ya.ConfigError):
+        q.groupdelay(0.6)

@@ -316,6 +316,16 @@ class FirFilter(_FirBase):
         _check(self._fn("get_coefficients")(self._h, _ptr(h), n))
         return h
 
+    def freqresponse(self, fc):                              # :325-328
+        H = np.zeros(1, np.complex64)
+        _check(self._fn("freqresponse")(self._h, fc, _ptr(H)))
+        return H[0]
+
+    def groupdelay(self, fc):                                # :339-342
+        d = C.c_float()
+        _check(self._fn("groupdelay")(self._h, fc, C.byref(d)))
+        return d.value
+
     def set_kernel(self, choice):
         """0 auto, 1 general direct form, 4 overlap-save fast convolution; crcf also 2 register-sliding and
         3 MFMA Toeplitz direct forms (include/yagi_hip.h)."""
@@ -362,6 +372,11 @@ class FirDecimationFilter(_FirBase):
 
     def execute_block_dev(self, x_dev, n, y_dev):
         _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def freqresp(self, fc):                                  # firdecim.rs:164-168
+        H = np.zeros(1, np.complex64)
+        _check(self._fn("freqresp")(self._h, fc, _ptr(H)))
+        return H[0]
 
 
 class FirPfbFilter(_FirBase):

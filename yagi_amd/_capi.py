@@ -74,6 +74,8 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     p = f"yagi_hip_firfilt_{_k}_"
     _sig(p + "create", vp, sz, pvp)
     _sig(p + "create_kaiser", sz, f32, f32, f32, pvp)
+    _sig(p + "freqresponse", vp, f32, vp)
+    _sig(p + "groupdelay", vp, f32, vp)
     _sig(p + "create_rect", sz, pvp)
     _sig(p + "create_dc_blocker", sz, f32, pvp)
     _sig(p + "create_notch", sz, f32, f32, pvp)
@@ -105,6 +107,7 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute", vp, vp, sz, vp)
     _sig(p + "execute_block", vp, vp, sz, sz, vp)
     _sig(p + "execute_block_dev", vp, vp, sz, vp)
+    _sig(f"yagi_hip_firdecim_{_k}_freqresp", vp, f32, vp)
     p = f"yagi_hip_firpfb_{_k}_"
     _sig(p + "create", sz, vp, sz, pvp)
     _sig(p + "create_kaiser", sz, sz, f32, f32, pvp)

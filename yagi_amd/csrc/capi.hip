@@ -670,6 +670,40 @@ static int notch_taps(size_t m, float as_, float f0, std::vector<cf32> &h) {
     return YAGI_OK;
 }
 
+// freqresponse (design/mod.rs:666-675): H(fc) = sum_i h[i] e^{-j 2 pi fc i}, the phasor in f64 rounded to f32, the sum in
+// Complex32; fir_group_delay (:687-704): Re(sum_i i h[i] e^{+j 2 pi fc i} / sum_i h[i] e^{+j 2 pi fc i}) on the real parts
+static cf32 cx_val(float v) { return cf32{v, 0.0f}; }
+static cf32 cx_val(cf32 v) { return v; }
+template <class C>
+static cf32 taps_freqresponse(const std::vector<C> &h, float fc) {
+    cf32 acc{0.0f, 0.0f};
+    for (size_t i = 0; i < h.size(); ++i) {
+        const double a = -2.0 * M_PI * (double)fc * (double)i;
+        const cf32 e{(float)std::cos(a), (float)std::sin(a)}, v = cx_val(h[i]);
+        acc.re += v.re * e.re - v.im * e.im;
+        acc.im += v.re * e.im + v.im * e.re;
+    }
+    return acc;
+}
+static cf32 cx_mul(cf32 a, cf32 b) { return cf32{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <class C>
+static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
+    if (h.empty()) return fail(YAGI_ERR_CONFIG, "fir_group_delay(), length must be greater than zero");
+    if (fc < -0.5f || fc > 0.5f) return fail(YAGI_ERR_CONFIG, "fir_group_delay(), _fc must be in [-0.5,0.5]");
+    cf32 t0{0.f, 0.f}, t1{0.f, 0.f};
+    for (size_t i = 0; i < h.size(); ++i) {
+        const float a = 2.0f * 3.14159265358979323846f * fc * (float)i, hr = cx_val(h[i]).re;
+        const cf32 e{std::cos(a), std::sin(a)};
+        t0.re += hr * e.re * (float)i;
+        t0.im += hr * e.im * (float)i;
+        t1.re += hr * e.re;
+        t1.im += hr * e.im;
+    }
+    const float den = t1.re * t1.re + t1.im * t1.im;
+    *out = (t0.re * t1.re + t0.im * t1.im) / den;
+    return YAGI_OK;
+}
+
 #define YAGI_FIR_IMPL(K, KT, T, C)                                                                  \
     struct yagi_hip_firfilt_##K##_s : FirFilt<KT> {};                                               \
     struct yagi_hip_firdecim_##K##_s : FirDecim<KT> {};                                             \
@@ -813,6 +847,17 @@ static int notch_taps(size_t m, float as_, float f0, std::vector<cf32> &h) {
         std::memcpy(h, q->h.data(), (size_t)q->L * sizeof(C));                                      \
         return YAGI_OK;                                                                             \
     }                                                                                               \
+    int yagi_hip_firfilt_##K##_freqresponse(yagi_hip_firfilt_##K q, float fc, yagi_cf32 *H) {       \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(H);                                                                               \
+        *H = cx_mul(taps_freqresponse(q->h, fc), cx_val(q->scale));                                 \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firfilt_##K##_groupdelay(yagi_hip_firfilt_##K q, float fc, float *delay) {         \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(delay);                                                                           \
+        return taps_groupdelay(q->h, fc, delay);                                                    \
+    }                                                                                               \
                                                                                                     \
     int yagi_hip_firdecim_##K##_create(size_t M, const C *h, size_t h_len,                          \
                                        yagi_hip_firdecim_##K *q) {                                  \
@@ -879,6 +924,12 @@ static int notch_taps(size_t m, float as_, float f0, std::vector<cf32> &h) {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(s);                                                                               \
         *s = q->scale;                                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_firdecim_##K##_freqresp(yagi_hip_firdecim_##K q, float fc, yagi_cf32 *H) {         \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(H);                                                                               \
+        *H = cx_mul(taps_freqresponse(q->h, fc), cx_val(q->scale));                                 \
         return YAGI_OK;                                                                             \
     }                                                                                               \
     int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y) {     \
