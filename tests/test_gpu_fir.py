@@ -480,3 +480,34 @@ def test_freqresponse_and_groupdelay(ya, kind):
     assert abs(sym.groupdelay(0.05) - 20.0) <= 1e-3
     with pytest.raises(ya.ConfigError):
         q.groupdelay(0.6)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_randomised_shapes_vs_f64(ya, oracle, kind):
+    """seeded sweep over filter length, block length, split points, scale and kernel choice (lengths 1..700, blocks
+    1..9000): every kernel against the f64 truth, with the stream cut at random places so that state is carried"""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        L = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 700]))
+        n = int(rng.integers(1, 9000))
+        h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n)
+        scale = (rng.standard_normal() + 1j * rng.standard_normal()) if kind == "cccf" else float(rng.standard_normal())
+        truth = oracle.fir_block_f64(kind, h, x, scale=scale)
+        choices = [0, 1, 4] + ([2, 3] if kind == "crcf" and L <= 256 else [])
+        cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, 3)) | {0, n})
+        for choice in choices:
+            q = ya.FirFilter(kind, h)
+            q.set_scale(scale)
+            q.set_kernel(choice)
+            got = np.concatenate([q.execute_block(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a])
+            bound = fir_bound(kind, h, x) * max(1.0, abs(scale)) + 1e-30
+            assert np.max(np.abs(got - truth)) <= bound, (case, L, n, choice)
+            assert rel_l2(got, truth) <= 3e-6, (case, L, n, choice)
+        M = int(rng.integers(2, 7))
+        nd = n // M
+        if nd:
+            d = ya.FirDecimationFilter(kind, M, h)
+            d.set_scale(scale)
+            k = int(rng.integers(0, nd + 1))
+            got = np.concatenate([d.execute_block(x[: k * M], k), d.execute_block(x[k * M: nd * M], nd - k)])
+            assert rel_l2(got, oracle.fir_block_f64(kind, h, x[: nd * M], M=M, scale=scale)) <= 3e-6, (case, L, n, M)
