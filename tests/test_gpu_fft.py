@@ -178,3 +178,17 @@ def test_fft_round_trip_whole_buffer(ya, n, total):
     e_X = np.sum(np.abs(X).astype(np.float64) ** 2)
     e_x = np.sum(np.abs(x).astype(np.float64) ** 2)
     assert abs(e_X / (n * e_x) - 1.0) <= 1e-6
+
+
+def test_fft_every_small_size_and_random_large_sizes(ya):
+    """every n in 1..160 and 60 seeded sizes up to 40000 (register kernels, mixed radix, direct-sum primes, Bluestein,
+    four-step -- whatever the plan picks), forward and backward, against numpy's f64 FFT"""
+    rng = np.random.default_rng(7)
+    sizes = list(range(1, 161)) + sorted(int(v) for v in rng.integers(161, 40001, 60))
+    for n in sizes:
+        x = ((rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n)) * np.sqrt(0.5)).astype(np.complex64)
+        for d, ref in ((ya.Direction.Forward, np.fft.fft), (ya.Direction.Backward, lambda v: np.fft.ifft(v) * len(v))):
+            got = ya.Fft(n, d).run_batch(x)
+            for b in range(2):
+                truth = ref(x[b * n:(b + 1) * n].astype(np.complex128))
+                assert rel_l2(got[b], truth) <= 1e-5, (n, d, b)
