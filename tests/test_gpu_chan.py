@@ -370,3 +370,34 @@ def test_firpfbch2_perfect_reconstruction(ya, M, m, tol_db):
     d = 2 * M * m - M // 2 + 1
     err = np.linalg.norm(y[d:] - x[: n - d]) / np.linalg.norm(x[: n - d])
     assert 20 * np.log10(err) <= tol_db, 20 * np.log10(err)
+
+
+def test_channelizer_randomised_shapes(ya, oracle):
+    """seeded sweep over channel counts (powers of two on the column / wide kernels, anything else on the tiled ones),
+    branch lengths and frame counts, analyzers and the firpfbch synthesizer against the restatements, with a cut"""
+    rng = np.random.default_rng(99)
+    Ms = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 6, 10, 12, 20, 48, 96, 100, 250]
+    for case in range(36):
+        M = int(rng.choice(Ms))
+        m = int(rng.choice([1, 2, 3, 4, 8]))
+        if M * m > 4096:
+            m = 2
+        nfr = int(rng.integers(64, 400))
+        h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
+        x = oracle.gen_complex(1000 + case, nfr * M)
+        k = int(rng.integers(1, nfr))
+        q = ya.FirPfbCh(M, 2 * m, h)
+        got = np.concatenate([q.analyzer_execute(x[: k * M]), q.analyzer_execute(x[k * M:])])
+        assert rel_l2(got, oracle.FirPfbCh(M, 2 * m, h).analyzer_execute(x)) <= 3e-6, ("ch", M, m, nfr)
+        if case % 3 == 0 and nfr * M <= 60000:
+            got = np.concatenate([q.synthesizer_execute(x[: k * M]), q.synthesizer_execute(x[k * M:])])
+            assert rel_l2(got, oracle.FirPfbCh(M, 2 * m, h).synthesizer_execute(x)) <= 3e-6, ("syn", M, m, nfr)
+        if M % 2 == 0:
+            h2 = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
+            h2 = (h2 * M / h2.sum()).astype(np.float32)
+            ns = 2 * (nfr // 2)
+            x2 = x[: ns * (M // 2)]
+            k2 = 2 * int(rng.integers(1, ns // 2))
+            q2 = ya.FirPfbCh2(M, m, h2)
+            got = np.concatenate([q2.analyzer_execute(x2[: k2 * (M // 2)]), q2.analyzer_execute(x2[k2 * (M // 2):])])
+            assert rel_l2(got, oracle.FirPfbCh2(M, m, h2).analyzer_execute(x2)) <= 3e-6, ("ch2", M, m, ns)
