@@ -574,11 +574,22 @@ static int dotprod_dev(const A *a, const B *b, size_t n, O *y, hipStream_t st) {
     YG_TRY(require_device());
     const size_t np = dotprod_num_partials(n);
     if (np == 1) return launch_dotprod<A, B, O, float>(a, b, n, false, 1.0f, y, y, st);
-    // multi-workgroup case needs scratch for the partials; it lives for the duration of the call
-    DevBuf part;
-    YG_TRY(part.alloc(np * sizeof(O)));
-    YG_TRY((launch_dotprod<A, B, O, float>(a, b, n, false, 1.0f, part.as<O>(), y, st)));
-    YG_HIP(hipStreamSynchronize(st));
+    // multi-workgroup case needs scratch for the partials: one grow-only buffer per host thread and device stream
+    // user, kept for the life of the process (a per-call hipMalloc / hipFree pair costs more than the reduction of
+    // 2^24 elements and forces a device synchronisation); calls on one stream are ordered, so reuse is safe there,
+    // and concurrent streams of one thread are serialised by the event below
+    struct Scratch { void *p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
+    static thread_local Scratch sc;
+    const size_t need = np * sizeof(O);
+    if (sc.done) YG_HIP(hipStreamWaitEvent(st, sc.done, 0));           // previous user of the scratch (any stream)
+    else YG_HIP(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    if (need > sc.bytes) {
+        if (sc.p) { YG_HIP(hipDeviceSynchronize()); YG_HIP(hipFree(sc.p)); sc.p = nullptr; sc.bytes = 0; }
+        YG_HIP(hipMalloc(&sc.p, need + need / 2));
+        sc.bytes = need + need / 2;
+    }
+    YG_TRY((launch_dotprod<A, B, O, float>(a, b, n, false, 1.0f, static_cast<O *>(sc.p), y, st)));
+    YG_HIP(hipEventRecord(sc.done, st));
     return YAGI_OK;
 }
 template <class A, class B, class O>
