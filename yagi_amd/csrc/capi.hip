@@ -193,9 +193,11 @@ int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
     if (conv) {
         YG_TRY(prepare_conv());
         if constexpr (K::id == 0)
-            YG_TRY(launch_fir_rrrf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st));
+            YG_TRY(launch_fir_rrrf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
         else
-            YG_TRY(launch_fir_cccf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st));
+            YG_TRY(launch_fir_cccf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
+        w.flip();                                   // the kernel's last workgroup wrote the next window
+        return YAGI_OK;
     } else {
         YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, 1, scale, y, n, st)));
     }
@@ -208,7 +210,9 @@ int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
     if (conv) {
         YG_TRY(prepare_conv());
-        YG_TRY(launch_fir_crcf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st));
+        YG_TRY(launch_fir_crcf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
+        w.flip();
+        return YAGI_OK;
     } else if (kernel_choice == 3 && Lm)
         YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st));
     else if (slide && Lp <= kSlideMaxTaps)

@@ -71,15 +71,16 @@ int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int
 // x[-pre .. x_avail) must be readable (chunked processing of one long block); ny outputs are produced.
 int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
                             float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
-                            hipStream_t st);
+                            hipStream_t st, cf32 *win_next = nullptr);
+// win_next (optional): receives the filter window after the call, the last L samples of win ++ x[0, x_avail)
 // same kernel for complex taps (hs = FFT of the complex taps, complex scale) and for real samples (two
 // blocks per transform as its real and imaginary parts)
 int launch_fir_cccf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
                             cf32 scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
-                            hipStream_t st);
+                            hipStream_t st, cf32 *win_next = nullptr);
 int launch_fir_rrrf_fftconv(const float *win, const float *x, size_t pre, size_t x_avail, const cf32 *hs,
                             float scale, int L, const cf32 *twf, const cf32 *twb, float *y, size_t ny,
-                            hipStream_t st);
+                            hipStream_t st, float *win_next = nullptr);
 
 // frequency-domain form of the firfilt_crcf -> 4096-pt FFT stream (1 <= L <= 257): FFT{h}.FFT{x_f} + FFT{boundary
 // correction}; gcorr[j] = h[L-1-j] (j < L-1, zero-padded to 256 floats); win_next <- last L samples of x.

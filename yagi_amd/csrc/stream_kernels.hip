@@ -409,11 +409,20 @@ __global__ void __launch_bounds__(256)
 firfilt_fftconv_kernel(const void *__restrict__ win_, const void *__restrict__ x_, long long pre,
                        long long x_avail, const float2 *__restrict__ hs, float2 sc, int L, int V,
                        const float2 *__restrict__ twf, const float2 *__restrict__ twb,
-                       void *__restrict__ y_, size_t ny) {
+                       void *__restrict__ y_, size_t ny, void *__restrict__ win_next_) {
     constexpr bool REAL = KIND == kConvRrrf;
     using T = typename std::conditional<REAL, float, float2>::type;
     const T *win = static_cast<const T *>(win_), *x = static_cast<const T *>(x_);
     T *y = static_cast<T *>(y_);
+    // the last workgroup also writes the filter window after this call: the last L samples of win ++ x[0, x_avail)
+    // (saves the separate update launch; win_next may be null)
+    if (win_next_ && blockIdx.x == gridDim.x - 1) {
+        T *wn = static_cast<T *>(win_next_);
+        for (int j = threadIdx.x; j < L; j += 256) {
+            const long long c = x_avail + j;                     // index into win ++ x
+            wn[j] = (c < (long long)L) ? win[c] : x[c - L];
+        }
+    }
     __shared__ float2 lds[kFft4096LdsFloat2];
     const size_t k0 = (REAL ? 2 : 1) * (size_t)blockIdx.x;            // first conv block of this workgroup
     const long long base = (long long)k0 * V - (L - 1);
@@ -473,7 +482,7 @@ firfilt_fftconv_kernel(const void *__restrict__ win_, const void *__restrict__ x
 
 template <int KIND, class T>
 static int launch_fir_fftconv_t(const T *win, const T *x, size_t pre, size_t x_avail, const cf32 *hs, cf32 scale,
-                                int L, const cf32 *twf, const cf32 *twb, T *y, size_t ny, hipStream_t st) {
+                                int L, const cf32 *twf, const cf32 *twb, T *y, size_t ny, hipStream_t st, T *win_next) {
     if (ny == 0) return YAGI_OK;
     if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
     const int V = 4096 - (L - 1);
@@ -483,25 +492,25 @@ static int launch_fir_fftconv_t(const T *win, const T *x, size_t pre, size_t x_a
     firfilt_fftconv_kernel<KIND><<<(unsigned)nwg, 256, 0, st>>>(
         win, x, (long long)pre, (long long)x_avail, reinterpret_cast<const float2 *>(hs),
         make_float2(scale.re / 4096.0f, scale.im / 4096.0f), L, V, reinterpret_cast<const float2 *>(twf),
-        reinterpret_cast<const float2 *>(twb), y, ny);
+        reinterpret_cast<const float2 *>(twb), y, ny, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
 int launch_fir_crcf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
                             float scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
-                            hipStream_t st) {
-    return launch_fir_fftconv_t<kConvCrcf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st);
+                            hipStream_t st, cf32 *win_next) {
+    return launch_fir_fftconv_t<kConvCrcf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st, win_next);
 }
 int launch_fir_cccf_fftconv(const cf32 *win, const cf32 *x, size_t pre, size_t x_avail, const cf32 *hs,
                             cf32 scale, int L, const cf32 *twf, const cf32 *twb, cf32 *y, size_t ny,
-                            hipStream_t st) {
-    return launch_fir_fftconv_t<kConvCccf>(win, x, pre, x_avail, hs, scale, L, twf, twb, y, ny, st);
+                            hipStream_t st, cf32 *win_next) {
+    return launch_fir_fftconv_t<kConvCccf>(win, x, pre, x_avail, hs, scale, L, twf, twb, y, ny, st, win_next);
 }
 int launch_fir_rrrf_fftconv(const float *win, const float *x, size_t pre, size_t x_avail, const cf32 *hs,
                             float scale, int L, const cf32 *twf, const cf32 *twb, float *y, size_t ny,
-                            hipStream_t st) {
-    return launch_fir_fftconv_t<kConvRrrf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st);
+                            hipStream_t st, float *win_next) {
+    return launch_fir_fftconv_t<kConvRrrf>(win, x, pre, x_avail, hs, cf32{scale, 0.f}, L, twf, twb, y, ny, st, win_next);
 }
 
 // M = 1 crcf block FIR with the sliding kernel; taps_pad = h zero-padded to Lp = roundup(L, 32)
