@@ -131,6 +131,28 @@ def test_firfilt_integer_inputs_bit_exact(ya, oracle, kind):
                 assert np.array_equal(np.concatenate([a, b]), want)
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("L", [1, 7, 8, 9, 17, 63, 64, 300, 1025])
+def test_firfilt_register_window_kernel(ya, oracle, kind, L):
+    """Blocks of >= 512 samples take the register-window direct kernel (8 consecutive outputs per lane), shorter
+    ones the interleaved-output kernel; both add the taps in the same order, so a stream cut either way must
+    give the same bits, and both must meet the f64 truth."""
+    rng = np.random.default_rng(7000 + L)
+    n = 2 * 2048 + 2048 + 513 + 512 + 2049
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n)
+    scale = (0.5 + 0.25j) if kind == "cccf" else -0.5
+    q = ya.FirFilter(kind, h)
+    q.set_scale(scale)
+    cuts = np.cumsum([0, 2 * 2048, 2048, 513, 512, 2049])
+    big = np.concatenate([q.execute_block(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    q.reset()
+    small = np.concatenate([q.execute_block(x[a:a + 500]) for a in range(0, n, 500)])
+    assert np.array_equal(big, small)
+    truth = oracle.fir_block_f64(kind, h, x, scale=scale)
+    assert np.max(np.abs(big - truth)) <= fir_bound(kind, h, x) * abs(scale) * 1.5 + 1e-30
+    assert rel_l2(big, truth) <= 2e-6
+
+
 @pytest.mark.parametrize("L", [1, 3, 16, 63, 64, 65, 100, 128, 129, 200, 255, 256])
 def test_firfilt_crcf_mfma_kernel_lengths(ya, oracle, L):
     """MFMA Toeplitz form (kernel 3) across the padded-length classes 64/128/256 and ragged blocks"""

@@ -116,6 +116,106 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// M = 1 direct form with register reuse (all three type combinations): a lane owns 8 CONSECUTIVE outputs and walks
+// the taps with an 8-sample register window that slides by one sample per tap -- one LDS read per 8 multiply-
+// accumulates instead of one per MAC (the interleaved-output kernel above is bound by exactly that read).
+// Tile = 256 lanes x 8 outputs; the span is staged with one pad element after every 8 samples, so that the 64 lanes
+// of a wave (8 samples = 9 slots apart) hit distinct banks.  The filter is treated as Lp = roundup(L, 8) taps, the
+// extra ones zero (they read up to 7 samples further back, which the span provides); taps come through the scalar
+// cache 8 at a time.  Same sums in the same tap order as fir_block_kernel (bit-identical results).
+// ---------------------------------------------------------------------------------------------
+constexpr int kConsecR = 8, kConsecTile = 256 * kConsecR;
+__device__ __forceinline__ int consec_pad(int i) { return i + (i >> 3); }
+
+template <class K>
+__global__ void __launch_bounds__(256)
+fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                  const typename K::C *__restrict__ taps, int L, typename K::C scale,
+                  typename K::T *__restrict__ y, size_t ny) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    const int Lp = (L + 7) & ~7;
+    const size_t o0 = (size_t)blockIdx.x * kConsecTile;
+    const int nt = (int)((ny - o0) < (size_t)kConsecTile ? (ny - o0) : (size_t)kConsecTile);
+    const long long base = (long long)o0 - (Lp - 1);            // stream index of span sample 0
+    const int span = kConsecTile + Lp - 1;
+    // X = win ++ x; indices before the window (only the zero taps reach them) and past the end of x read as zero
+    if (base >= 0 && base + span <= (long long)ny) {
+        const T *src = x + base;
+        for (int i = threadIdx.x; i < span; i += 256) xs[consec_pad(i)] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const long long idx = base + i;
+            T v = zero_of<T>();
+            if (idx >= 0) { if (idx < (long long)ny) v = x[idx]; }
+            else if (idx >= -(long long)L) v = win[L + idx];
+            xs[consec_pad(i)] = v;
+        }
+    }
+    __syncthreads();
+    const int l = threadIdx.x;
+    T acc[kConsecR], w[kConsecR];
+#pragma unroll
+    for (int r = 0; r < kConsecR; ++r) acc[r] = zero_of<T>();
+    // at tap k (j = Lp-1-k) output r of the lane needs span sample 8l + r + j (slot 9l + q + (q >> 3), q = r + j),
+    // kept in w[(r + j) & 7]
+    const T *xl = xs + 9 * l;
+    {
+        const int j = Lp - 1;                                    // j & 7 == 7
+#pragma unroll
+        for (int r = 1; r < kConsecR; ++r) w[(r + 7) & 7] = xl[(r + j) + ((r + j) >> 3)];
+    }
+    auto eight_taps = [&](const C (&hk)[8], int k0) {
+        const int jb = Lp - 8 - k0;                              // multiple of 8: j = jb + 7 - u
+        const T *xb = xl + jb + (jb >> 3);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            w[(7 - u) & 7] = xb[7 - u];                          // the window's new lowest sample (r = 0)
+#pragma unroll
+            for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + 7 - u) & 7], hk[u]);
+        }
+    };
+    int k0 = 0;
+    for (; k0 + 8 <= L; k0 += 8) {
+        C hk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hk[u] = taps[k0 + u];
+        eight_taps(hk, k0);
+    }
+    if (k0 < L) {
+        C hk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hk[u] = (k0 + u < L) ? taps[k0 + u] : zero_of<C>();
+        eight_taps(hk, k0);
+    }
+    const int o = kConsecR * l;
+    if (o + kConsecR <= nt) {
+#pragma unroll
+        for (int r = 0; r < kConsecR; ++r) y[o0 + o + r] = mul(acc[r], scale);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kConsecR; ++r)
+            if (o + r < nt) y[o0 + o + r] = mul(acc[r], scale);
+    }
+}
+
+template <class K>
+static int launch_fir_consec(const typename K::T *win, const typename K::T *x, const typename K::C *taps, int L,
+                             typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+    using T = typename K::T;
+    const int Lp = (L + 7) & ~7;
+    const int span = kConsecTile + Lp - 1;
+    const size_t lds = (size_t)(span + (span >> 3) + 1) * sizeof(T);
+    const size_t nblk = (ny + kConsecTile - 1) / kConsecTile;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    fir_consec_kernel<K><<<(unsigned)nblk, 256, lds, st>>>(win, x, taps, L, scale, y, ny);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
                      int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
@@ -123,6 +223,9 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
     using T = typename K::T;
     if (ny == 0) return YAGI_OK;
     if (L <= 0 || M <= 0) return fail(YAGI_ERR_INTERNAL, "fir_block: bad L/M");
+    // M = 1 with a block long enough to fill tiles, span within 48 KiB: the register-window kernel
+    if (M == 1 && ny >= 512 && ((size_t)(kConsecTile + L + 8) * 9 / 8 + 1) * sizeof(T) <= kFirLdsBudget && x_len == 0)
+        return launch_fir_consec<K>(win, x, taps, L, scale, y, ny, st);
     // largest tile (<= R*256 outputs) whose phase-split span fits the LDS budget
     auto need = [&](int t) {
         const size_t pitch = (size_t)((((long long)(t - 1) * M + L + M - 1) / M) | 1);
