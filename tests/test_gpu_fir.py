@@ -151,6 +151,15 @@ def test_firfilt_register_window_kernel(ya, oracle, kind, L):
     truth = oracle.fir_block_f64(kind, h, x, scale=scale)
     assert np.max(np.abs(big - truth)) <= fir_bound(kind, h, x) * abs(scale) * 1.5 + 1e-30
     assert rel_l2(big, truth) <= 2e-6
+    # a NaN in the stream poisons outputs s0 .. s0+L-1 and nothing else (taps past L are skipped, not zeroed);
+    # crcf's default is the sliding kernel, whose zero-padded taps widen the region -- kernel 1 is the exact one
+    xn = x.copy()
+    xn[5000] = np.nan
+    q.reset()
+    q.set_kernel(1)
+    gn = q.execute_block(xn)
+    bad = np.flatnonzero(np.isnan(gn.real) if np.iscomplexobj(gn) else np.isnan(gn))
+    assert np.array_equal(bad, np.arange(5000, min(5000 + L, n)))
 
 
 @pytest.mark.parametrize("L", [1, 3, 16, 63, 64, 65, 100, 128, 129, 200, 255, 256])
@@ -313,6 +322,42 @@ def test_firdecim_random_vs_f64(ya, oracle, kind, M, L, n):
     assert np.array_equal(q.execute_block(e, 10), c.execute_block(e, 10))
     q.reset()
     np.testing.assert_allclose(q.execute_block(x[:20 * M], 20), truth[:20], atol=fir_bound(kind, h, x))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("M,L", [(2, 2), (2, 9), (2, 65), (3, 64), (3, 100), (4, 65), (4, 129), (5, 7), (7, 50), (8, 129),
+                                 (8, 257), (12, 200), (12, 400), (16, 33), (16, 513)])
+def test_firdecim_register_window_kernel(ya, oracle, kind, M, L):
+    """Blocks of >= 512 outputs with >= 32 taps per decimation phase take the per-phase register-window kernel
+    (workgroups of 256 / 128 / 64 lanes by what fits the LDS; YAGI_HIP_DECIM_WINDOW_MIN_STEPS=0 sends every shape
+    here through it), the rest the general kernel; the stream is cut at ragged places, a NaN placed in
+    the input must poison exactly the outputs whose window holds it, and integers stay exact."""
+    rng = np.random.default_rng(9000 + 37 * M + L)
+    cuts = np.cumsum([0, 4096, 2048, 513, 700, 512, 2049, 100])
+    n = int(cuts[-1])
+    h, x = rand_taps(rng, kind, L), rand_samples(rng, kind, n * M)
+    q = ya.FirDecimationFilter(kind, M, h)
+    q.set_scale(0.5)
+    got = np.concatenate([q.execute_block(x[a * M:b * M], b - a) for a, b in zip(cuts[:-1], cuts[1:])])
+    truth = oracle.fir_block_f64(kind, h, x, M=M, n=n, scale=0.5)
+    assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x)
+    assert rel_l2(got, truth) <= 2e-6
+    # NaN containment: output o sees samples M*o-(L-1) .. M*o
+    xn = x.copy()
+    s0 = 3000 * M + 1
+    xn[s0] = np.nan
+    q.reset()
+    gn = q.execute_block(xn, n)
+    bad = np.flatnonzero(np.isnan(gn.real) if np.iscomplexobj(gn) else np.isnan(gn))
+    o = np.arange(n)
+    want = np.flatnonzero((M * o >= s0) & (M * o - (L - 1) <= s0))
+    assert np.array_equal(bad, want)
+    # integers: exact whatever the summation order
+    T, Cdt = ya.KINDS[kind]
+    hi = rng.integers(-4, 5, L).astype(Cdt)
+    xi = rng.integers(-8, 9, 2048 * M).astype(T)
+    qi = ya.FirDecimationFilter(kind, M, hi)
+    assert np.array_equal(qi.execute_block(xi, 2048), oracle.fir_block_f64(kind, hi, xi, M=M, n=2048).astype(T))
 
 
 @pytest.mark.parametrize("kind", KINDS)

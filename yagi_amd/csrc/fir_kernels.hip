@@ -17,6 +17,8 @@
 #include <type_traits>
 
 #include "devmath.hpp"
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace yagi {
@@ -121,9 +123,9 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
 // the taps with an 8-sample register window that slides by one sample per tap -- one LDS read per 8 multiply-
 // accumulates instead of one per MAC (the interleaved-output kernel above is bound by exactly that read).
 // Tile = 256 lanes x 8 outputs; the span is staged with one pad element after every 8 samples, so that the 64 lanes
-// of a wave (8 samples = 9 slots apart) hit distinct banks.  The filter is treated as Lp = roundup(L, 8) taps, the
-// extra ones zero (they read up to 7 samples further back, which the span provides); taps come through the scalar
-// cache 8 at a time.  Same sums in the same tap order as fir_block_kernel (bit-identical results).
+// of a wave (8 samples = 9 slots apart) hit distinct banks.  The window geometry is that of Lp = roundup(L, 8) taps
+// (the span reaches up to 7 samples further back); the taps past L are skipped, never multiplied, so a NaN in the
+// stream poisons exactly the outputs it poisons in the reference.  Taps come through the scalar cache 8 at a time.  Same sums in the same tap order as fir_block_kernel (bit-identical results).
 // ---------------------------------------------------------------------------------------------
 constexpr int kConsecR = 8, kConsecTile = 256 * kConsecR;
 __device__ __forceinline__ int consec_pad(int i) { return i + (i >> 3); }
@@ -168,14 +170,17 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
 #pragma unroll
         for (int r = 1; r < kConsecR; ++r) w[(r + 7) & 7] = xl[(r + j) + ((r + j) >> 3)];
     }
-    auto eight_taps = [&](const C (&hk)[8], int k0) {
+    auto eight_taps = [&](const C (&hk)[8], int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int jb = Lp - 8 - k0;                              // multiple of 8: j = jb + 7 - u
         const T *xb = xl + jb + (jb >> 3);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             w[(7 - u) & 7] = xb[7 - u];                          // the window's new lowest sample (r = 0)
+            if (FULL || k0 + u < L) {                            // wave-uniform: taps past L are skipped, not zeroed
 #pragma unroll
-            for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + 7 - u) & 7], hk[u]);
+                for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + 7 - u) & 7], hk[u]);
+            }
         }
     };
     int k0 = 0;
@@ -183,13 +188,13 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
         C hk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) hk[u] = taps[k0 + u];
-        eight_taps(hk, k0);
+        eight_taps(hk, k0, std::true_type{});
     }
     if (k0 < L) {
         C hk[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) hk[u] = (k0 + u < L) ? taps[k0 + u] : zero_of<C>();
-        eight_taps(hk, k0);
+        for (int u = 0; u < 8; ++u) hk[u] = taps[k0 + u < L ? k0 + u : L - 1];
+        eight_taps(hk, k0, std::false_type{});
     }
     const int o = kConsecR * l;
     if (o + kConsecR <= nt) {
@@ -216,6 +221,114 @@ static int launch_fir_consec(const typename K::T *win, const typename K::T *x, c
     return YAGI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decimator (M >= 2) with the same register window, one decimation phase at a time: the taps of phase p are
+// h[L-1-p-M*i], i = 0.., and at step i output o reads row p of the phase-split span at index o + i -- so a lane
+// that owns 8 consecutive outputs slides an 8-sample window along the row, one LDS read per 8 MACs.  Rows carry
+// the 9/8 padding of fir_consec_kernel.  The sum runs phase by phase instead of in tap order (same products,
+// f32 rounding may differ from fir_block_kernel in the last bit; exact on integer data).  NT lanes per
+// workgroup (tile = 8*NT outputs) so that the M rows fit the LDS budget.
+// ---------------------------------------------------------------------------------------------
+template <class K, int NT>
+__global__ void __launch_bounds__(NT)
+fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                        const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
+                        typename K::T *__restrict__ y, size_t ny, int pitch) {
+    using T = typename K::T;
+    using C = typename K::C;
+    constexpr int TILE = NT * kConsecR;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);
+    const size_t o0 = (size_t)blockIdx.x * TILE;
+    const int nt = (int)((ny - o0) < (size_t)TILE ? (ny - o0) : (size_t)TILE);
+    const long long base = (long long)o0 * M - (L - 1);         // stream index of row 0, entry 0
+    const long long xlen = (long long)ny * M;
+    const int ni = (L + M - 1) / M;                              // steps of the longest row
+    const int total = (TILE + ni - 1) * M;                       // entries any (o, i) of a full tile can reach
+    // entry e = jj*M + ph; (jj, ph) advance by NT entries per trip without a division
+    const int djj = NT / M, dph = NT - djj * M;
+    int jj = (int)threadIdx.x / M, ph = (int)threadIdx.x - jj * M;
+    if (base >= 0 && base + total <= xlen) {                     // block-uniform: every entry lies inside x
+        const T *src = x + base;
+        for (int e = threadIdx.x; e < total; e += NT) {
+            xs[ph * pitch + consec_pad(jj)] = src[e];
+            jj += djj; ph += dph;
+            if (ph >= M) { ph -= M; ++jj; }
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += NT) {
+            const long long idx = base + e;
+            T v = zero_of<T>();
+            if (idx < 0) v = win[L + idx];
+            else if (idx < xlen) v = x[idx];
+            xs[ph * pitch + consec_pad(jj)] = v;
+            jj += djj; ph += dph;
+            if (ph >= M) { ph -= M; ++jj; }
+        }
+    }
+    __syncthreads();
+    const int l = threadIdx.x;
+    T acc[kConsecR], w[kConsecR];
+#pragma unroll
+    for (int r = 0; r < kConsecR; ++r) acc[r] = zero_of<T>();
+    const int np_phases = M < L ? M : L;
+#pragma unroll 1
+    for (int ph = 0; ph < np_phases; ++ph) {
+        const int n_p = (L - 1 - ph) / M + 1;
+        const T *row = xs + ph * pitch + 9 * l;                  // slot of row index 8l + q: 9l + q + (q >> 3)
+        const C *tp = taps + (L - 1 - ph);                       // step i multiplies by tp[-M*i]
+#pragma unroll
+        for (int r = 0; r < kConsecR - 1; ++r) w[r] = row[r];    // w[(r + i) & 7] = row entry 8l + r + i
+        auto eight_steps = [&](int i0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            C hk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = (FULL || i0 + u < n_p) ? i0 + u : n_p - 1;
+                hk[u] = tp[-(long long)M * i];
+            }
+            const T *rb = row + i0 + (i0 >> 3);                  // i0 is a multiple of 8
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                w[(7 + u) & 7] = rb[(7 + u) + ((7 + u) >> 3)];   // the window's new highest sample (r = 7)
+                if (FULL || i0 + u < n_p) {
+#pragma unroll
+                    for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + u) & 7], hk[u]);
+                }
+            }
+        };
+        int i0 = 0;
+        for (; i0 + 8 <= n_p; i0 += 8) eight_steps(i0, std::true_type{});
+        if (i0 < n_p) eight_steps(i0, std::false_type{});
+    }
+    const int o = kConsecR * l;
+#pragma unroll
+    for (int r = 0; r < kConsecR; ++r)
+        if (o + r < nt) y[o0 + o + r] = mul(acc[r], scale);
+}
+
+// row pitch of the decimator kernel: entries any step can touch (tile + steps rounded up to 8, + the 8 of the
+// last window refill), padded 9/8, odd so that the M rows start on different banks
+static inline int decim_consec_pitch(int tile, int L, int M) {
+    const int ni = (L + M - 1) / M;
+    const int n = tile + ((ni + 7) & ~7) + 8;
+    return (n + (n >> 3) + 1) | 1;
+}
+
+template <class K, int NT>
+static int launch_fir_decim_consec(const typename K::T *win, const typename K::T *x, const typename K::C *taps, int L,
+                                   int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+    using T = typename K::T;
+    constexpr int TILE = NT * kConsecR;
+    const int pitch = decim_consec_pitch(TILE, L, M);
+    const size_t lds = (size_t)M * pitch * sizeof(T);
+    const size_t nblk = (ny + TILE - 1) / TILE;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    fir_decim_consec_kernel<K, NT><<<(unsigned)nblk, NT, lds, st>>>(win, x, taps, L, M, scale, y, ny, pitch);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
                      int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
@@ -226,6 +339,20 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
     // M = 1 with a block long enough to fill tiles, span within 48 KiB: the register-window kernel
     if (M == 1 && ny >= 512 && ((size_t)(kConsecTile + L + 8) * 9 / 8 + 1) * sizeof(T) <= kFirLdsBudget && x_len == 0)
         return launch_fir_consec<K>(win, x, taps, L, scale, y, ny, st);
+    // decimators: the same register window per decimation phase, with the widest workgroup whose M rows fit
+    // (pays once a phase has enough taps to amortise its window fill; YAGI_HIP_DECIM_WINDOW_MIN_STEPS overrides)
+    static const int min_steps = [] {
+        const char *e = getenv("YAGI_HIP_DECIM_WINDOW_MIN_STEPS");
+        return e ? atoi(e) : 32;
+    }();
+    if (M >= 2 && L >= M && L / M >= min_steps && ny >= 512 && x_len == 0) {
+        auto fits = [&](int nt) {
+            return (size_t)M * decim_consec_pitch(nt * kConsecR, L, M) * sizeof(T) <= kFirLdsBudget;
+        };
+        if (fits(256)) return launch_fir_decim_consec<K, 256>(win, x, taps, L, M, scale, y, ny, st);
+        if (fits(128)) return launch_fir_decim_consec<K, 128>(win, x, taps, L, M, scale, y, ny, st);
+        if (fits(64)) return launch_fir_decim_consec<K, 64>(win, x, taps, L, M, scale, y, ny, st);
+    }
     // largest tile (<= R*256 outputs) whose phase-split span fits the LDS budget
     auto need = [&](int t) {
         const size_t pitch = (size_t)((((long long)(t - 1) * M + L + M - 1) / M) | 1);
