@@ -68,6 +68,27 @@ def test_vs_oracle(ya, oracle, kind, P, Q, m):
     assert rel_l2(q.execute_block(x[:Q], 1), ref.execute_block(x[:Q], 1)) <= 1e-6
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("P,Q,m", [(3, 5, 15), (5, 3, 6), (3, 2, 8), (2, 3, 4), (7, 4, 5), (1, 8, 3), (9, 1, 2), (16, 15, 4)])
+def test_many_blocks_cut_both_ways(ya, oracle, kind, P, Q, m):
+    """several LDS tiles per call with a ragged last tile: the same stream cut into long and short calls must
+    give the same bits; integer data must match the restated schedule exactly"""
+    rng = np.random.default_rng(31 * P + Q)
+    nblk = 256 * 3 + 77
+    h, x = rand_taps(rng, kind, 2 * P * m), rand_samples(rng, kind, nblk * Q)
+    q = ya.Rresamp(kind, P, Q, m, h)
+    q.set_scale(0.5)
+    big = np.concatenate([q.execute_block(x[:300 * Q], 300), q.execute_block(x[300 * Q:], nblk - 300)])
+    q.reset()
+    small = np.concatenate([q.execute_block(x[b * Q:min(b + 100, nblk) * Q], min(100, nblk - b))
+                            for b in range(0, nblk, 100)])
+    assert np.array_equal(big, small)
+    hi, xi = int_taps(rng, kind, 2 * P * m), int_samples(rng, kind, nblk * Q)
+    ref = oracle.Rresamp(kind, P, Q, m, hi)
+    qi = ya.Rresamp(kind, P, Q, m, hi)
+    assert np.array_equal(qi.execute_block(xi, nblk), ref.execute_block(xi, nblk))
+
+
 @pytest.mark.parametrize("P", [1, 2, 3, 6, 8, 9])
 def test_partition(ya, P, Q=5, m=15, n=20):
     """rresamp.rs:198-238 (autotest_rresamp_crcf_part_P*_Q5): one 2n-block run == n blocks, then a second

@@ -426,12 +426,66 @@ firpfb_all_kernel(const typename K::T *__restrict__ win, const typename K::T *__
     }
 }
 
+// Few branches (interpolators: nf = 2 .. 16): with a lane per (sample, branch) the 64 lanes of a wave share 64/nf
+// samples and nf taps -- two LDS reads per MAC and a tile of only 64 samples.  Here a lane owns ONE input sample
+// and walks the branches four at a time: one LDS read (consecutive across lanes) per 4 MACs, the taps through
+// the scalar cache (branch and tap index are wave-uniform), 256 samples per workgroup, and each lane stores 4
+// consecutive outputs.  Same tap order as firpfb_all_kernel.
+template <class K>
+__global__ void __launch_bounds__(256)
+firpfb_fewbranch_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
+                        const typename K::C *__restrict__ hb, int nf, int Ls, typename K::C scale,
+                        typename K::T *__restrict__ y, size_t n) {
+    using T = typename K::T;
+    using C = typename K::C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T *xs = reinterpret_cast<T *>(smem);                       // 256 + Ls - 1 samples
+    const size_t n0 = (size_t)blockIdx.x * 256;
+    const int nt = (int)((n - n0) < (size_t)256 ? (n - n0) : (size_t)256);
+    const long long base = (long long)n0 - (Ls - 1);
+    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    __syncthreads();
+    const int nl = threadIdx.x;
+    if (nl >= nt) return;
+    const T *xr = xs + nl + (Ls - 1);                          // tap k reads xr[-k]
+    T *yo = y + (n0 + nl) * (size_t)nf;
+    int g0 = 0;
+    for (; g0 + 4 <= nf; g0 += 4) {
+        const C *h0 = hb + (size_t)g0 * Ls;
+        T acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = zero_of<T>();
+#pragma unroll 4
+        for (int k = 0; k < Ls; ++k) {
+            const T sk = xr[-k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = mac(acc[j], sk, h0[(size_t)j * Ls + k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yo[g0 + j] = mul(acc[j], scale);
+    }
+    for (; g0 < nf; ++g0) {                                    // the last nf % 4 branches
+        const C *h0 = hb + (size_t)g0 * Ls;
+        T acc = zero_of<T>();
+        for (int k = 0; k < Ls; ++k) acc = mac(acc, xr[-k], h0[k]);
+        yo[g0] = mul(acc, scale);
+    }
+}
+
 template <class K>
 int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
                       int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st) {
     using T = typename K::T;
     using C = typename K::C;
     if (n == 0) return YAGI_OK;
+    if (nf <= 16 && (size_t)(256 + Ls - 1) * sizeof(T) <= kFirLdsBudget) {
+        const size_t nblk = (n + 255) / 256;
+        if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+        firpfb_fewbranch_kernel<K><<<(unsigned)nblk, 256, (size_t)(256 + Ls - 1) * sizeof(T), st>>>(win, x, hb, nf, Ls,
+                                                                                                   scale, y, n);
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
     const size_t xs_bytes = ((size_t)(kPfbTN + Ls - 1) * sizeof(T) + 15) / 16 * 16;
     if (xs_bytes > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "branch filters too long (%d taps)", Ls);
     const size_t tap_bytes = (size_t)nf * Ls * sizeof(C);
