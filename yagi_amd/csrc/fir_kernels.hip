@@ -142,12 +142,28 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
     const int Lp = (L + 7) & ~7;
     const size_t o0 = (size_t)blockIdx.x * kConsecTile;
     const int nt = (int)((ny - o0) < (size_t)kConsecTile ? (ny - o0) : (size_t)kConsecTile);
-    const long long base = (long long)o0 - (Lp - 1);            // stream index of span sample 0
-    const int span = kConsecTile + Lp - 1;
-    // X = win ++ x; indices before the window (only the zero taps reach them) and past the end of x read as zero
-    if (base >= 0 && base + span <= (long long)ny) {
-        const T *src = x + base;
-        for (int i = threadIdx.x; i < span; i += 256) xs[consec_pad(i)] = src[i];
+    const long long base = (long long)o0 - Lp;                  // stream index of span sample 0: a multiple of 8,
+    const int span = kConsecTile + Lp;                          // so an aligned x is read 16 bytes per lane
+    // X = win ++ x; indices before the window (no tap reaches them) and past the end of x read as zero
+    if (base >= 0 && base + span <= (long long)ny && (reinterpret_cast<unsigned long long>(x) & 15ull) == 0) {
+        constexpr int VEC = 16 / sizeof(T);
+        const float4 *src = reinterpret_cast<const float4 *>(x + base);
+        const int nvec = span / VEC;
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += 4 * 256) {  // four 16-byte loads in flight per lane
+            float4 q[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) q[b] = src[v0 + 256 * b < nvec ? v0 + 256 * b : nvec - 1];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int v = v0 + 256 * b;
+                if (v < nvec) {
+                    T *dst = xs + consec_pad(v * VEC);           // VEC divides 8: the elements share a pad group
+                    const T *e = reinterpret_cast<const T *>(&q[b]);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) dst[c] = e[c];
+                }
+            }
+        }
     } else {
         for (int i = threadIdx.x; i < span; i += 256) {
             const long long idx = base + i;
@@ -162,13 +178,13 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
     T acc[kConsecR], w[kConsecR];
 #pragma unroll
     for (int r = 0; r < kConsecR; ++r) acc[r] = zero_of<T>();
-    // at tap k (j = Lp-1-k) output r of the lane needs span sample 8l + r + j (slot 9l + q + (q >> 3), q = r + j),
-    // kept in w[(r + j) & 7]
+    // at tap k (j = Lp-1-k) output r of the lane needs span sample 8l + q with q = r + j + 1, i.e. slot
+    // 9l + q + (q >> 3); it is kept in w[(r + j) & 7]
     const T *xl = xs + 9 * l;
     {
         const int j = Lp - 1;                                    // j & 7 == 7
 #pragma unroll
-        for (int r = 1; r < kConsecR; ++r) w[(r + 7) & 7] = xl[(r + j) + ((r + j) >> 3)];
+        for (int r = 1; r < kConsecR; ++r) w[(r + 7) & 7] = xl[(r + j + 1) + ((r + j + 1) >> 3)];
     }
     auto eight_taps = [&](const C (&hk)[8], int k0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -176,7 +192,7 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
         const T *xb = xl + jb + (jb >> 3);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            w[(7 - u) & 7] = xb[7 - u];                          // the window's new lowest sample (r = 0)
+            w[(7 - u) & 7] = xb[(8 - u) + ((8 - u) >> 3)];       // the window's new lowest sample (r = 0, q = j + 1)
             if (FULL || k0 + u < L) {                            // wave-uniform: taps past L are skipped, not zeroed
 #pragma unroll
                 for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + 7 - u) & 7], hk[u]);
@@ -212,7 +228,7 @@ static int launch_fir_consec(const typename K::T *win, const typename K::T *x, c
                              typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
     using T = typename K::T;
     const int Lp = (L + 7) & ~7;
-    const int span = kConsecTile + Lp - 1;
+    const int span = kConsecTile + Lp;
     const size_t lds = (size_t)(span + (span >> 3) + 1) * sizeof(T);
     const size_t nblk = (ny + kConsecTile - 1) / kConsecTile;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
