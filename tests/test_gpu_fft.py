@@ -137,11 +137,12 @@ def test_fft_large_batch_on_device(ya, oracle, n):
         assert rel_l2(dy.to_numpy(n, offset=b * n), truth) <= 1e-5, b
 
 
-@pytest.mark.parametrize("n", [16384, 32768, 1 << 20, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4])
+@pytest.mark.parametrize("n", [16384, 32768, 65536, 1 << 17, 1 << 20, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4])
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_beyond_one_workgroup(ya, n, direction):
-    """n > 8192: powers of two by the four-step form (transposes around the register kernels), every other size by
-    Bluestein over a power of two (itself four-step above 8192).  Truth: numpy's f64 FFT of the same f32 samples."""
+    """n > 8192: 2^14 .. 2^16 by the two-launch column / row form (no transposes), larger powers of two and smooth
+    sizes by the four-step form (transposes around the register kernels), every other size by Bluestein over a
+    power of two.  Truth: numpy's f64 FFT of the same f32 samples."""
     rng = np.random.default_rng(n)
     batch = 2
     x = ((rng.standard_normal(batch * n) + 1j * rng.standard_normal(batch * n)) * np.sqrt(0.5)).astype(np.complex64)
@@ -151,6 +152,11 @@ def test_fft_beyond_one_workgroup(ya, n, direction):
         xb = x[b * n:(b + 1) * n].astype(np.complex128)
         truth = np.fft.fft(xb) if d == ya.Direction.Forward else np.fft.ifft(xb) * n
         assert rel_l2(got[b], truth) <= 1e-5, b
+    if n in (16384, 65536):                                   # in place on the device
+        dx = ya.DeviceArray.from_numpy(x)
+        ya.Fft(n, d).run_batch_dev(dx, dx, batch)
+        ya.synchronize()
+        assert np.array_equal(dx.to_numpy().reshape(batch, n), got.reshape(batch, n))
 
 
 def test_fft_size_limits(ya):

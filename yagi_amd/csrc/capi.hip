@@ -310,7 +310,7 @@ struct FftPlan {
     DevBuf bs_w, bs_bf, bs_twf, bs_twb, bs_scratch;      // Bluestein resources (sizes with a large prime factor)
     std::unique_ptr<FftPlan> bs_fwd, bs_bwd;             // Bluestein over m > 8192: the m-point plans
     std::unique_ptr<FftPlan> fs_p1, fs_p2;               // four-step: the n1- and n2-point plans
-    DevBuf fs_scratch;
+    DevBuf fs_scratch, fs_wn;
 };
 
 // radix list of the mixed-radix kernel: the power of two in as few passes as radix <= 16 allows (bits spread
@@ -381,6 +381,11 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
             p.d.fs_p2 = &p.fs_p2->d;
             p.d.fs_scratch = p.fs_scratch.as<cf32>();
             p.d.fs_chunk = (int)chunk;
+            auto small_pow2 = [](size_t v) { return v >= 64 && v <= 256 && (v & (v - 1)) == 0; };
+            if (small_pow2(n1) && small_pow2(n2)) {            // two-launch form (fft_kernels.hip: fft_twopass_kernel)
+                YG_TRY(make_twiddles((int)n, dir, p.fs_wn));
+                p.d.fs_wn = p.fs_wn.as<cf32>();
+            }
             return YAGI_OK;
         }
         if (pow2) return fail(YAGI_ERR_INTERNAL, "no four-step split for %zu", n);

@@ -7,6 +7,7 @@
 //                    registers + 34 KiB LDS (fft_core.hpp).
 //   fft_n256m_kernel, fft8192_kernel   the same register scheme for 256..2048 and 8192
 //   fft_pow2_kernel  other powers of two (N <= 128): LDS-staged register Stockham passes
+//   fft_twopass_kernel  2^14 .. 2^16 points: column pass + row pass over the LDS Stockham core (two HBM round trips)
 //   fft_mixed_kernel any other N <= 8192: mixed-radix Stockham passes in LDS over the plan's factor
 //                    list, register butterflies for radix 16/8/4/2/3/5/7, direct R-term sums (exact
 //                    table twiddles, index arithmetic mod N) for any other prime factor.
@@ -235,6 +236,99 @@ fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// n = n1 n2, both powers of two <= 256 (2^14 .. 2^16 points): the four-step form in TWO launches, no transposes.
+// x viewed as [n1][n2]:
+//   pass 0 (columns): a workgroup takes nfr consecutive columns c0.. -- rows of nfr consecutive points in
+//           memory -- transforms them over n1 and writes S[k1][c] = W_n^{k1 c} FFT_n1{x[.][c]}[k1] back in place;
+//   pass 1 (rows):    a workgroup takes nfr consecutive rows k1 of S, transforms them over n2 and writes
+//           X[k2 n1 + k1]: runs of nfr consecutive points again.
+// Two HBM round trips instead of five.  Both passes run the LDS Stockham core transform-fastest (the nfr
+// columns / rows are its transforms), so the strided side of each pass is what its lanes already do.
+// ---------------------------------------------------------------------------------------------
+template <int SIGN, int MODE>
+__global__ void __launch_bounds__(256)
+fft_twopass_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *__restrict__ out,
+                   const float2 *__restrict__ tw, const float2 *__restrict__ wn, int n1, int n2, int nfr, int lgnfr,
+                   int pitch) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *bufA = reinterpret_cast<float2 *>(smem);
+    float2 *bufB = bufA + (size_t)nfr * pitch;
+    float2 *twl = bufB + (size_t)nfr * pitch;
+    for (int e = threadIdx.x; e < N; e += 256) twl[e] = tw[e];
+    const size_t n = (size_t)n1 * n2;
+    // pass 0: W_n^m = W_n^{256 (m >> 8)} W_n^{m & 255} from two 256-entry LDS tables (a per-point gather from the
+    // n-entry table in global memory costs more than the transform: 64 distinct lines per wave access)
+    float2 *wlo = twl + N, *whi = wlo + 256;
+    if (MODE == 0) {
+        wlo[threadIdx.x] = wn[threadIdx.x];
+        whi[threadIdx.x] = wn[((size_t)threadIdx.x << 8) & (n - 1)];
+    }
+    const float2 *src = in + blockIdx.y * n;
+    float2 *dst = out + blockIdx.y * n;
+    const int t0 = blockIdx.x * nfr;                             // first column (pass 0) / row (pass 1) of the tile
+    const int lgN = 31 - __builtin_clz((unsigned)N);
+    const int total = nfr * N;
+    if (MODE == 0) {
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int tr = e & (nfr - 1), p = e >> lgnfr;
+            bufA[tr * pitch + p] = src[(size_t)p * n2 + t0 + tr];
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int tr = e >> lgN, p = e & (N - 1);
+            bufA[tr * pitch + p] = src[(size_t)(t0 + tr) * n2 + p];
+        }
+    }
+    __syncthreads();
+    const float2 *res = lds_fft_pow2<SIGN, true>(bufA, bufB, N, nfr, plan, twl, 1, false, pitch, lgnfr);
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int tr = e & (nfr - 1), k = e >> lgnfr;
+        float2 v = res[tr * pitch + k];
+        if (MODE == 0) {
+            const unsigned m = ((unsigned)k * (unsigned)(t0 + tr)) & (unsigned)(n - 1);
+            dst[(size_t)k * n2 + t0 + tr] = cmul(v, cmul(whi[m >> 8], wlo[m & 255u]));
+        } else {
+            dst[(size_t)k * n1 + t0 + tr] = v;
+        }
+    }
+}
+
+static int launch_fft_two_pass(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    const int n1 = p.fs_n1, n2 = p.fs_n2;
+    const size_t n = (size_t)p.n;
+    float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch);
+    const float2 *wn = reinterpret_cast<const float2 *>(p.fs_wn);
+    const bool fwd = p.dir == YAGI_FFT_FORWARD;
+    auto pass = [&](int mode, int N, const float2 *tw, const float2 *src, float2 *dst, unsigned nb) -> int {
+        const int nfr = 2048 / N;                                 // 16 columns / rows (128-byte runs) at N = 128, 8 at 256
+        int lgnfr = 0;
+        while ((1 << lgnfr) < nfr) ++lgnfr;
+        const int pitch = frfast_pitch(N, nfr);
+        const size_t lds = (2 * (size_t)nfr * pitch + (size_t)N + (mode == 0 ? 512 : 0)) * sizeof(float2);
+        const Pow2Plan plan = make_pow2_plan(N);
+        const dim3 grid((unsigned)((mode == 0 ? n2 : n1) / nfr), nb);
+        if (mode == 0) {
+            if (fwd) fft_twopass_kernel<-1, 0><<<grid, 256, lds, st>>>(N, plan, src, dst, tw, wn, n1, n2, nfr, lgnfr, pitch);
+            else fft_twopass_kernel<+1, 0><<<grid, 256, lds, st>>>(N, plan, src, dst, tw, wn, n1, n2, nfr, lgnfr, pitch);
+        } else {
+            if (fwd) fft_twopass_kernel<-1, 1><<<grid, 256, lds, st>>>(N, plan, src, dst, tw, wn, n1, n2, nfr, lgnfr, pitch);
+            else fft_twopass_kernel<+1, 1><<<grid, 256, lds, st>>>(N, plan, src, dst, tw, wn, n1, n2, nfr, lgnfr, pitch);
+        }
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    };
+    const size_t chunk = (size_t)p.fs_chunk * 2;                 // the whole scratch holds the one intermediate
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const unsigned nb = (unsigned)((batch - b0) < chunk ? (batch - b0) : chunk);
+        const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
+        float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
+        YG_TRY(pass(0, n1, reinterpret_cast<const float2 *>(p.fs_p1->tw), src, s0, nb));
+        YG_TRY(pass(1, n2, reinterpret_cast<const float2 *>(p.fs_p2->tw), s0, dst, nb));
+    }
+    return YAGI_OK;
+}
+
 static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int n1 = p.fs_n1, n2 = p.fs_n2;
     const size_t n = (size_t)p.n;
@@ -308,6 +402,7 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         return YAGI_OK;
     }
     if (p.bs_m) return launch_fft_bluestein(p, in, out, batch, st);
+    if (p.fs_n1 && p.fs_wn) return launch_fft_two_pass(p, in, out, batch, st);
     if (p.fs_n1) return launch_fft_four_step(p, in, out, batch, st);
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_INTERNAL, "fft size %d has no plan resources", p.n);
     if (p.n == 8192) {

@@ -109,6 +109,7 @@ struct FftPlanDev {
     const FftPlanDev *fs_p1 = nullptr, *fs_p2 = nullptr;      // host pointers: the n1- and n2-point plans
     cf32 *fs_scratch = nullptr;      // 2 * fs_chunk * n points
     int fs_chunk = 0;
+    const cf32 *fs_wn = nullptr;     // W_n table when both factors are powers of two <= 256: two-launch form, no transposes
 };
 constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
 constexpr size_t kFftMaxPow2 = (size_t)1 << 24;    // largest power of two (four-step); any other n up to 2^23 (Bluestein)
