@@ -317,12 +317,16 @@ YAGI_RRESAMP_API(rrrf, float, float)
 YAGI_RRESAMP_API(crcf, yagi_cf32, float)
 YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
 
-/* Which kernel execute_block uses.  0 = auto (always a direct form), 1 = general direct-form kernel
- * (fir_kernels.hip), 4 = overlap-save fast convolution (<= 2049 taps; stream_kernels.hip).
- * crcf also: 2 = register-sliding direct form (<= 1024 taps), 3 = MFMA Toeplitz direct form (<= 256 taps).
+/* Which kernel execute_block uses.  0 = auto (always a direct form), 1 = general direct-form kernels
+ * (fir_kernels.hip: register-window kernel for blocks >= 512 samples, interleaved-output kernel below; both add
+ * the taps in the reference's order and never touch a tap past h_len, so a NaN poisons exactly h_len outputs),
+ * 4 = overlap-save fast convolution (<= 2049 taps; stream_kernels.hip).
+ * crcf also: 2 = hand-scheduled register-sliding direct form (<= 1024 taps; the crcf auto choice), 3 = MFMA
+ * Toeplitz direct form (<= 256 taps); these two multiply zero-padded taps (a NaN's footprint is rounded up to
+ * 32 taps).
  * The direct forms evaluate the reference's sums (exact on integer-valued data); the fast convolution agrees
  * with them to f32 rounding (rel. L2 <= 2e-6 against the f64 truth), like the reference's own FftFilt, and is
- * 2.5x (crcf, 256 taps) to 10x (rrrf, cccf) faster on long blocks. */
+ * 2.5x (rrrf, crcf; 256 taps) to 5x (cccf, 256 taps) faster on long blocks, a tie for short filters (63 taps). */
 int yagi_hip_firfilt_rrrf_set_kernel(yagi_hip_firfilt_rrrf q, int choice);
 int yagi_hip_firfilt_crcf_set_kernel(yagi_hip_firfilt_crcf q, int choice);
 int yagi_hip_firfilt_cccf_set_kernel(yagi_hip_firfilt_cccf q, int choice);
