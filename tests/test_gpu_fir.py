@@ -326,11 +326,12 @@ def test_firdecim_random_vs_f64(ya, oracle, kind, M, L, n):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("M,L", [(2, 2), (2, 9), (2, 65), (3, 64), (3, 100), (4, 65), (4, 129), (5, 7), (7, 50), (8, 129),
-                                 (8, 257), (12, 200), (12, 400), (16, 33), (16, 513)])
+                                 (8, 257), (8, 2049), (12, 200), (12, 400), (16, 33), (16, 513)])
 def test_firdecim_register_window_kernel(ya, oracle, kind, M, L):
-    """Blocks of >= 512 outputs with >= 32 taps per decimation phase take the per-phase register-window kernel
-    (workgroups of 256 / 128 / 64 lanes by what fits the LDS; YAGI_HIP_DECIM_WINDOW_MIN_STEPS=0 sends every shape
-    here through it), the rest the general kernel; the stream is cut at ragged places, a NaN placed in
+    """Blocks of >= 512 outputs with >= 8 taps per decimation phase take the per-phase register-window kernel
+    (8- or 4-sample window, workgroups of 256 / 128 / 64 lanes by phase length and what fits the LDS;
+    YAGI_HIP_DECIM_WINDOW_MIN_STEPS=0 sends every shape here through it), the rest the general kernel; the
+    stream is cut at ragged places, a NaN placed in
     the input must poison exactly the outputs whose window holds it, and integers stay exact."""
     rng = np.random.default_rng(9000 + 37 * M + L)
     cuts = np.cumsum([0, 4096, 2048, 513, 700, 512, 2049, 100])

@@ -245,14 +245,15 @@ static int launch_fir_consec(const typename K::T *win, const typename K::T *x, c
 // f32 rounding may differ from fir_block_kernel in the last bit; exact on integer data).  NT lanes per
 // workgroup (tile = 8*NT outputs) so that the M rows fit the LDS budget.
 // ---------------------------------------------------------------------------------------------
-template <class K, int NT>
+template <class K, int NT, int R>
 __global__ void __launch_bounds__(NT)
 fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                         const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
                         typename K::T *__restrict__ y, size_t ny, int pitch) {
     using T = typename K::T;
     using C = typename K::C;
-    constexpr int TILE = NT * kConsecR;
+    constexpr int TILE = NT * R, LG = R == 8 ? 3 : 2;
+    static_assert(R == 8 || R == 4, "window of 4 or 8 samples");
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);
     const size_t o0 = (size_t)blockIdx.x * TILE;
@@ -267,7 +268,7 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
     if (base >= 0 && base + total <= xlen) {                     // block-uniform: every entry lies inside x
         const T *src = x + base;
         for (int e = threadIdx.x; e < total; e += NT) {
-            xs[ph * pitch + consec_pad(jj)] = src[e];
+            xs[ph * pitch + jj + (jj >> LG)] = src[e];
             jj += djj; ph += dph;
             if (ph >= M) { ph -= M; ++jj; }
         }
@@ -277,70 +278,70 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
             T v = zero_of<T>();
             if (idx < 0) v = win[L + idx];
             else if (idx < xlen) v = x[idx];
-            xs[ph * pitch + consec_pad(jj)] = v;
+            xs[ph * pitch + jj + (jj >> LG)] = v;
             jj += djj; ph += dph;
             if (ph >= M) { ph -= M; ++jj; }
         }
     }
     __syncthreads();
     const int l = threadIdx.x;
-    T acc[kConsecR], w[kConsecR];
+    T acc[R], w[R];
 #pragma unroll
-    for (int r = 0; r < kConsecR; ++r) acc[r] = zero_of<T>();
+    for (int r = 0; r < R; ++r) acc[r] = zero_of<T>();
     const int np_phases = M < L ? M : L;
 #pragma unroll 1
     for (int ph = 0; ph < np_phases; ++ph) {
         const int n_p = (L - 1 - ph) / M + 1;
-        const T *row = xs + ph * pitch + 9 * l;                  // slot of row index 8l + q: 9l + q + (q >> 3)
+        const T *row = xs + ph * pitch + (R + 1) * l;            // slot of row index R l + q: (R+1) l + q + (q >> LG)
         const C *tp = taps + (L - 1 - ph);                       // step i multiplies by tp[-M*i]
 #pragma unroll
-        for (int r = 0; r < kConsecR - 1; ++r) w[r] = row[r];    // w[(r + i) & 7] = row entry 8l + r + i
+        for (int r = 0; r < R - 1; ++r) w[r] = row[r];           // w[(r + i) & (R-1)] = row entry R l + r + i
         auto eight_steps = [&](int i0, auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
-            C hk[8];
+            C hk[R];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < R; ++u) {
                 const int i = (FULL || i0 + u < n_p) ? i0 + u : n_p - 1;
                 hk[u] = tp[-(long long)M * i];
             }
-            const T *rb = row + i0 + (i0 >> 3);                  // i0 is a multiple of 8
+            const T *rb = row + i0 + (i0 >> LG);                 // i0 is a multiple of R
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                w[(7 + u) & 7] = rb[(7 + u) + ((7 + u) >> 3)];   // the window's new highest sample (r = 7)
+            for (int u = 0; u < R; ++u) {
+                w[(R - 1 + u) & (R - 1)] = rb[(R - 1 + u) + ((R - 1 + u) >> LG)];   // the window's new highest sample
                 if (FULL || i0 + u < n_p) {
 #pragma unroll
-                    for (int r = 0; r < kConsecR; ++r) acc[r] = mac(acc[r], w[(r + u) & 7], hk[u]);
+                    for (int r = 0; r < R; ++r) acc[r] = mac(acc[r], w[(r + u) & (R - 1)], hk[u]);
                 }
             }
         };
         int i0 = 0;
-        for (; i0 + 8 <= n_p; i0 += 8) eight_steps(i0, std::true_type{});
+        for (; i0 + R <= n_p; i0 += R) eight_steps(i0, std::true_type{});
         if (i0 < n_p) eight_steps(i0, std::false_type{});
     }
-    const int o = kConsecR * l;
+    const int o = R * l;
 #pragma unroll
-    for (int r = 0; r < kConsecR; ++r)
+    for (int r = 0; r < R; ++r)
         if (o + r < nt) y[o0 + o + r] = mul(acc[r], scale);
 }
 
 // row pitch of the decimator kernel: entries any step can touch (tile + steps rounded up to 8, + the 8 of the
 // last window refill), padded 9/8, odd so that the M rows start on different banks
-static inline int decim_consec_pitch(int tile, int L, int M) {
+static inline int decim_consec_pitch(int tile, int L, int M, int R) {
     const int ni = (L + M - 1) / M;
-    const int n = tile + ((ni + 7) & ~7) + 8;
-    return (n + (n >> 3) + 1) | 1;
+    const int n = tile + ((ni + R - 1) & ~(R - 1)) + R;
+    return (n + n / R + 1) | 1;
 }
 
-template <class K, int NT>
+template <class K, int NT, int R>
 static int launch_fir_decim_consec(const typename K::T *win, const typename K::T *x, const typename K::C *taps, int L,
                                    int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
     using T = typename K::T;
-    constexpr int TILE = NT * kConsecR;
-    const int pitch = decim_consec_pitch(TILE, L, M);
+    constexpr int TILE = NT * R;
+    const int pitch = decim_consec_pitch(TILE, L, M, R);
     const size_t lds = (size_t)M * pitch * sizeof(T);
     const size_t nblk = (ny + TILE - 1) / TILE;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    fir_decim_consec_kernel<K, NT><<<(unsigned)nblk, NT, lds, st>>>(win, x, taps, L, M, scale, y, ny, pitch);
+    fir_decim_consec_kernel<K, NT, R><<<(unsigned)nblk, NT, lds, st>>>(win, x, taps, L, M, scale, y, ny, pitch);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -356,18 +357,27 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
     if (M == 1 && ny >= 512 && ((size_t)(kConsecTile + L + 8) * 9 / 8 + 1) * sizeof(T) <= kFirLdsBudget && x_len == 0)
         return launch_fir_consec<K>(win, x, taps, L, scale, y, ny, st);
     // decimators: the same register window per decimation phase, with the widest workgroup whose M rows fit
-    // (pays once a phase has enough taps to amortise its window fill; YAGI_HIP_DECIM_WINDOW_MIN_STEPS overrides)
+    // (pays once a phase has enough taps to amortise its window fill: 8-sample window from 32 taps per phase,
+    // 4-sample window with full 256-lane workgroups from 8; YAGI_HIP_DECIM_WINDOW_MIN_STEPS overrides the 8)
     static const int min_steps = [] {
         const char *e = getenv("YAGI_HIP_DECIM_WINDOW_MIN_STEPS");
-        return e ? atoi(e) : 32;
+        return e ? atoi(e) : 8;
     }();
     if (M >= 2 && L >= M && L / M >= min_steps && ny >= 512 && x_len == 0) {
-        auto fits = [&](int nt) {
-            return (size_t)M * decim_consec_pitch(nt * kConsecR, L, M) * sizeof(T) <= kFirLdsBudget;
+        auto fits = [&](int nt, int r) {
+            return (size_t)M * decim_consec_pitch(nt * r, L, M, r) * sizeof(T) <= kFirLdsBudget;
         };
-        if (fits(256)) return launch_fir_decim_consec<K, 256>(win, x, taps, L, M, scale, y, ny, st);
-        if (fits(128)) return launch_fir_decim_consec<K, 128>(win, x, taps, L, M, scale, y, ny, st);
-        if (fits(64)) return launch_fir_decim_consec<K, 64>(win, x, taps, L, M, scale, y, ny, st);
+        const bool long_phase = L / M >= 32;
+        // short phases: measured wins for complex samples and for M <= 4 (rrrf M = 8, 16 taps per phase: the general
+        // kernel's 4-byte LDS reads are cheaper than eight window fills)
+        const bool short_ok = sizeof(T) == 8 || M <= 4;
+        if (long_phase && fits(256, 8)) return launch_fir_decim_consec<K, 256, 8>(win, x, taps, L, M, scale, y, ny, st);
+        if (long_phase || short_ok) {
+            if (fits(256, 4)) return launch_fir_decim_consec<K, 256, 4>(win, x, taps, L, M, scale, y, ny, st);
+            if (fits(128, 4)) return launch_fir_decim_consec<K, 128, 4>(win, x, taps, L, M, scale, y, ny, st);
+        }
+        if (long_phase && fits(64, 8)) return launch_fir_decim_consec<K, 64, 8>(win, x, taps, L, M, scale, y, ny, st);
+        if (long_phase && fits(64, 4)) return launch_fir_decim_consec<K, 64, 4>(win, x, taps, L, M, scale, y, ny, st);
     }
     // largest tile (<= R*256 outputs) whose phase-split span fits the LDS budget
     auto need = [&](int t) {
