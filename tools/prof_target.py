@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """profiling target: launch each selected kernel a few times (for rocprofv3 --pmc / --kernel-trace).
-usage: python3 tools/prof_target.py [fused fused2 fir2 fir3 fft fft_big chan1 chan2] """
+usage: python3 tools/prof_target.py [fused fused2 fir2 fir3 fft fft_big chan1 chan2 rrrf63 rrrf256 cccf256
+       decim4x257 decim8x513 interp4 fft16384 fft65536] """
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -33,6 +34,26 @@ for w in what:
     elif w == "chan2":
         c = ya.FirPfbCh2.new_kaiser(256, 4, 60.0); c.set_stream(st.cuda_stream)
         fn = lambda c=c: c.analyzer_execute_dev(x, n // 128, y)
+    elif w in ("rrrf63", "rrrf256", "cccf256"):
+        kind = w[:4]
+        L = int(w[4:])
+        hh = ya.fir_design_kaiser(L, 0.2, 60.0)
+        if kind == "cccf":
+            hh = (hh * np.exp(0.3j * np.arange(L))).astype(np.complex64)
+        q = ya.FirFilter(kind, hh); q.set_stream(st.cuda_stream)
+        xin, yout, cnt = (x.view(torch.float32), y.view(torch.float32), n) if kind == "rrrf" else (x, y, n)
+        fn = lambda q=q, xin=xin, yout=yout, cnt=cnt: q.execute_block_dev(xin, cnt, yout)
+    elif w in ("decim4x257", "decim8x513"):
+        M, L = (4, 257) if w == "decim4x257" else (8, 513)
+        d = ya.FirDecimationFilter("crcf", M, ya.fir_design_kaiser(L, 0.4 / M, 60.0)); d.set_stream(st.cuda_stream)
+        fn = lambda d=d, M=M: d.execute_block_dev(x, n // M, y)
+    elif w == "interp4":
+        fi = ya.FirInterpolationFilter.new_kaiser("crcf", 4, 8, 60.0); fi.set_stream(st.cuda_stream)
+        fn = lambda fi=fi: fi.execute_block_dev(x, n // 4, y)
+    elif w in ("fft16384", "fft65536"):
+        N = int(w[3:])
+        p = ya.Fft(N, ya.Direction.Forward)
+        fn = lambda p=p, N=N: p.run_batch_dev(x, y, n // N, st.cuda_stream)
     else:
         raise SystemExit(f"unknown target {w}")
     keep.append(fn)
