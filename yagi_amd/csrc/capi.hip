@@ -189,6 +189,7 @@ struct FirFilt {
 template <class K>
 int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
     YG_TRY(w.flush(st));
+    if (n == 0) return YAGI_OK;
     const bool conv = kernel_choice == 4 && L <= 2049;
     if (conv) {
         YG_TRY(prepare_conv());
@@ -198,14 +199,15 @@ int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
             YG_TRY(launch_fir_cccf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
         w.flip();                                   // the kernel's last workgroup wrote the next window
         return YAGI_OK;
-    } else {
-        YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, 1, scale, y, n, st)));
     }
-    return w.advance(x, n, st);
+    YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, 1, scale, y, n, st, 0, w.next())));
+    w.flip();                                       // the kernel's last workgroup wrote the next window
+    return YAGI_OK;
 }
 template <>
 int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
     YG_TRY(w.flush(st));
+    if (n == 0) return YAGI_OK;
     const bool conv = kernel_choice == 4 && L <= 2049;
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
     if (conv) {
@@ -215,10 +217,15 @@ int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
         return YAGI_OK;
     } else if (kernel_choice == 3 && Lm)
         YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st));
-    else if (slide && Lp <= kSlideMaxTaps)
-        YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st));
-    else
-        YG_TRY((launch_fir_block<CRCF>(w.dev(), x, taps.as<float>(), L, 1, scale, y, n, st)));
+    else if (slide && Lp <= kSlideMaxTaps) {
+        YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st, w.next()));
+        w.flip();                                   // the kernel's last workgroup wrote the next window
+        return YAGI_OK;
+    } else {
+        YG_TRY((launch_fir_block<CRCF>(w.dev(), x, taps.as<float>(), L, 1, scale, y, n, st, 0, w.next())));
+        w.flip();
+        return YAGI_OK;
+    }
     return w.advance(x, n, st);
 }
 
@@ -252,8 +259,10 @@ struct FirDecim {
     // n outputs from n*M device samples
     int block_dev(const T *x, size_t n, T *y) {
         YG_TRY(w.flush(st));
-        YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, M, scale, y, n, st)));
-        return w.advance(x, n * (size_t)M, st);
+        if (n == 0) return YAGI_OK;
+        YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, M, scale, y, n, st, 0, w.next())));
+        w.flip();                                   // the kernel's last workgroup wrote the next window
+        return YAGI_OK;
     }
 };
 

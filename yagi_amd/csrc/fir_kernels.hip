@@ -33,6 +33,19 @@ __device__ __forceinline__ T load_stream(const T *__restrict__ win, const T *__r
     return (idx < 0) ? win[L + idx] : x[idx];
 }
 
+// The state a Window<T> holds after the block (window.rs:77-85): new_win = last L samples of (win ++ x[0..n)).
+// Written by the LAST workgroup of the block's own kernel (reads only; `win_next` is the object's other window
+// buffer), which saves the separate 4-5 us window-update launch after every execute_block.
+template <class T>
+__device__ __forceinline__ void write_next_window(const T *__restrict__ win, const T *__restrict__ x, size_t n, int L,
+                                                  T *__restrict__ win_next) {
+    if (win_next == nullptr || blockIdx.x != gridDim.x - 1) return;
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        const size_t c = n + (size_t)j;            // index into win ++ x
+        win_next[j] = (c < (size_t)L) ? win[c] : x[c - (size_t)L];
+    }
+}
+
 // STAGE = span in LDS.  The span is stored de-interleaved by decimation phase, xs[phase][j] = X[base + j*M + phase]
 // (pitch P = ceil(span/M) + pad), so at tap k the 64 lanes of a wave -- 64 consecutive outputs, M samples
 // apart in the stream -- read 64 CONSECUTIVE LDS words of one phase row (with the plain layout a decimator
@@ -42,10 +55,12 @@ template <class K, bool STAGE>
 __global__ void __launch_bounds__(kFirBlock)
 fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                  const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
-                 typename K::T *__restrict__ y, size_t ny, int tile, long long x_len) {
+                 typename K::T *__restrict__ y, size_t ny, int tile, long long x_len,
+                 typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
+    write_next_window(win, x, ny * (size_t)M, L, win_next);
     const size_t o0 = (size_t)blockIdx.x * (size_t)tile;
     const int nt = (int)((ny - o0) < (size_t)tile ? (ny - o0) : (size_t)tile);
     const long long base = (long long)o0 * M - (L - 1);
@@ -134,11 +149,12 @@ template <class K>
 __global__ void __launch_bounds__(256)
 fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                   const typename K::C *__restrict__ taps, int L, typename K::C scale,
-                  typename K::T *__restrict__ y, size_t ny) {
+                  typename K::T *__restrict__ y, size_t ny, typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);
+    write_next_window(win, x, ny, L, win_next);
     const int Lp = (L + 7) & ~7;
     const size_t o0 = (size_t)blockIdx.x * kConsecTile;
     const int nt = (int)((ny - o0) < (size_t)kConsecTile ? (ny - o0) : (size_t)kConsecTile);
@@ -225,14 +241,15 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
 
 template <class K>
 static int launch_fir_consec(const typename K::T *win, const typename K::T *x, const typename K::C *taps, int L,
-                             typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+                             typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
+                             typename K::T *win_next) {
     using T = typename K::T;
     const int Lp = (L + 7) & ~7;
     const int span = kConsecTile + Lp;
     const size_t lds = (size_t)(span + (span >> 3) + 1) * sizeof(T);
     const size_t nblk = (ny + kConsecTile - 1) / kConsecTile;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    fir_consec_kernel<K><<<(unsigned)nblk, 256, lds, st>>>(win, x, taps, L, scale, y, ny);
+    fir_consec_kernel<K><<<(unsigned)nblk, 256, lds, st>>>(win, x, taps, L, scale, y, ny, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -249,13 +266,14 @@ template <class K, int NT, int R>
 __global__ void __launch_bounds__(NT)
 fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                         const typename K::C *__restrict__ taps, int L, int M, typename K::C scale,
-                        typename K::T *__restrict__ y, size_t ny, int pitch) {
+                        typename K::T *__restrict__ y, size_t ny, int pitch, typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     constexpr int TILE = NT * R, LG = R == 8 ? 3 : 2;
     static_assert(R == 8 || R == 4, "window of 4 or 8 samples");
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);
+    write_next_window(win, x, ny * (size_t)M, L, win_next);
     const size_t o0 = (size_t)blockIdx.x * TILE;
     const int nt = (int)((ny - o0) < (size_t)TILE ? (ny - o0) : (size_t)TILE);
     const long long base = (long long)o0 * M - (L - 1);         // stream index of row 0, entry 0
@@ -334,14 +352,15 @@ static inline int decim_consec_pitch(int tile, int L, int M, int R) {
 
 template <class K, int NT, int R>
 static int launch_fir_decim_consec(const typename K::T *win, const typename K::T *x, const typename K::C *taps, int L,
-                                   int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st) {
+                                   int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
+                                   typename K::T *win_next) {
     using T = typename K::T;
     constexpr int TILE = NT * R;
     const int pitch = decim_consec_pitch(TILE, L, M, R);
     const size_t lds = (size_t)M * pitch * sizeof(T);
     const size_t nblk = (ny + TILE - 1) / TILE;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    fir_decim_consec_kernel<K, NT, R><<<(unsigned)nblk, NT, lds, st>>>(win, x, taps, L, M, scale, y, ny, pitch);
+    fir_decim_consec_kernel<K, NT, R><<<(unsigned)nblk, NT, lds, st>>>(win, x, taps, L, M, scale, y, ny, pitch, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -349,13 +368,13 @@ static int launch_fir_decim_consec(const typename K::T *win, const typename K::T
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
                      int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
-                     size_t x_len) {
+                     size_t x_len, typename K::T *win_next) {
     using T = typename K::T;
     if (ny == 0) return YAGI_OK;
     if (L <= 0 || M <= 0) return fail(YAGI_ERR_INTERNAL, "fir_block: bad L/M");
     // M = 1 with a block long enough to fill tiles, span within 48 KiB: the register-window kernel
     if (M == 1 && ny >= 512 && ((size_t)(kConsecTile + L + 8) * 9 / 8 + 1) * sizeof(T) <= kFirLdsBudget && x_len == 0)
-        return launch_fir_consec<K>(win, x, taps, L, scale, y, ny, st);
+        return launch_fir_consec<K>(win, x, taps, L, scale, y, ny, st, win_next);
     // decimators: the same register window per decimation phase, with the widest workgroup whose M rows fit
     // (pays once a phase has enough taps to amortise its window fill: 8-sample window from 32 taps per phase,
     // 4-sample window with full 256-lane workgroups from 8; YAGI_HIP_DECIM_WINDOW_MIN_STEPS overrides the 8)
@@ -371,13 +390,13 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
         // short phases: measured wins for complex samples and for M <= 4 (rrrf M = 8, 16 taps per phase: the general
         // kernel's 4-byte LDS reads are cheaper than eight window fills)
         const bool short_ok = sizeof(T) == 8 || M <= 4;
-        if (long_phase && fits(256, 8)) return launch_fir_decim_consec<K, 256, 8>(win, x, taps, L, M, scale, y, ny, st);
+        if (long_phase && fits(256, 8)) return launch_fir_decim_consec<K, 256, 8>(win, x, taps, L, M, scale, y, ny, st, win_next);
         if (long_phase || short_ok) {
-            if (fits(256, 4)) return launch_fir_decim_consec<K, 256, 4>(win, x, taps, L, M, scale, y, ny, st);
-            if (fits(128, 4)) return launch_fir_decim_consec<K, 128, 4>(win, x, taps, L, M, scale, y, ny, st);
+            if (fits(256, 4)) return launch_fir_decim_consec<K, 256, 4>(win, x, taps, L, M, scale, y, ny, st, win_next);
+            if (fits(128, 4)) return launch_fir_decim_consec<K, 128, 4>(win, x, taps, L, M, scale, y, ny, st, win_next);
         }
-        if (long_phase && fits(64, 8)) return launch_fir_decim_consec<K, 64, 8>(win, x, taps, L, M, scale, y, ny, st);
-        if (long_phase && fits(64, 4)) return launch_fir_decim_consec<K, 64, 4>(win, x, taps, L, M, scale, y, ny, st);
+        if (long_phase && fits(64, 8)) return launch_fir_decim_consec<K, 64, 8>(win, x, taps, L, M, scale, y, ny, st, win_next);
+        if (long_phase && fits(64, 4)) return launch_fir_decim_consec<K, 64, 4>(win, x, taps, L, M, scale, y, ny, st, win_next);
     }
     // largest tile (<= R*256 outputs) whose phase-split span fits the LDS budget
     auto need = [&](int t) {
@@ -399,16 +418,16 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
     // x_len = samples readable at x (0 = unknown: the outputs' own span, ny*M)
     const long long xl = (long long)(x_len ? x_len : ny * (size_t)M);
     if (stage)
-        fir_block_kernel<K, true><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl);
+        fir_block_kernel<K, true><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl, win_next);
     else
-        fir_block_kernel<K, false><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl);
+        fir_block_kernel<K, false><<<(unsigned)nblk, kFirBlock, lds, st>>>(win, x, taps, L, M, scale, y, ny, tile, xl, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
-template int launch_fir_block<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t, size_t);
-template int launch_fir_block<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t, size_t);
-template int launch_fir_block<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t, size_t);
+template int launch_fir_block<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t, size_t, float *);
+template int launch_fir_block<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t, size_t, cf32 *);
+template int launch_fir_block<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t, size_t, cf32 *);
 
 // ---------------------------------------------------------------------------------------------
 // polyphase bank, all branches per pushed sample (interpolator form):

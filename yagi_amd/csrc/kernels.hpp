@@ -32,7 +32,9 @@ int launch_update_window(const T *old_win, const T *x, size_t n, int L, T *new_w
 template <class K>
 int launch_fir_block(const typename K::T *win, const typename K::T *x, const typename K::C *taps,
                      int L, int M, typename K::C scale, typename K::T *y, size_t ny, hipStream_t st,
-                     size_t x_len = 0 /* samples readable at x; 0 = ny*M */);
+                     size_t x_len = 0 /* samples readable at x; 0 = ny*M */,
+                     typename K::T *win_next = nullptr /* if set: receives the window after the block (last L samples of
+                                                          win ++ x[0..ny*M)), written by the kernel's last workgroup */);
 
 // polyphase bank, all branches per input sample: y[n*nf + i] = scale * sum_k hb[i][k] X[n-k]
 // branch taps hb laid out [nf][Ls] in natural (newest-first) order.
@@ -54,7 +56,7 @@ int launch_rresamp(const typename K::T *win, const typename K::T *x, const typen
 // taps_pad = h zero-padded to Lp = roundup(L, 32) floats.
 constexpr int kSlideMaxTaps = 1024;
 int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad, int L, int Lp,
-                          float scale, cf32 *y, size_t ny, hipStream_t st);
+                          float scale, cf32 *y, size_t ny, hipStream_t st, cf32 *win_next = nullptr);
 int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pad, const float *apack,
                             int L, int Lp, int Lm, float scale, const cf32 *tw4096, cf32 *spectra,
                             size_t nframes, int variant, hipStream_t st);

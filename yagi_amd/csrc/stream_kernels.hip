@@ -117,10 +117,17 @@ __device__ __forceinline__ void fir_tile_slide(float2 (&acc)[16], const float2 *
 __global__ void __launch_bounds__(256)
 firfilt_crcf_slide_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                           const float *__restrict__ taps_pad, int L, int Lp, float scale,
-                          float2 *__restrict__ y, size_t ny) {
+                          float2 *__restrict__ y, size_t ny, float2 *__restrict__ win_next) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
     float2 *ys = xs;                         // 4096 outputs, padded rows: reuses the span image once the FIR loop is done
+    // the window after the block = last L samples of (win ++ x), written by the last workgroup (saves the
+    // separate window-update launch: 4-5 us after every execute_block)
+    if (win_next != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int j = threadIdx.x; j < L; j += 256) {
+            const size_t c = ny + (size_t)j;
+            win_next[j] = (c < (size_t)L) ? win[c] : x[c - (size_t)L];
+        }
     // one tile per workgroup, no grid-stride loop (a loop makes the FFT twiddle / table loads loop-invariant
     // and LICM keeps them live across the FIR phase: +100 VGPRs in the fused kernels)
     {
@@ -515,7 +522,7 @@ int launch_fir_rrrf_fftconv(const float *win, const float *x, size_t pre, size_t
 
 // M = 1 crcf block FIR with the sliding kernel; taps_pad = h zero-padded to Lp = roundup(L, 32)
 int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad, int L, int Lp,
-                          float scale, cf32 *y, size_t ny, hipStream_t st) {
+                          float scale, cf32 *y, size_t ny, hipStream_t st, cf32 *win_next) {
     if (ny == 0) return YAGI_OK;
     if (Lp > kSlideMaxTaps || (Lp & 31)) return fail(YAGI_ERR_INTERNAL, "slide kernel: bad Lp %d", Lp);
     static bool raised = false;
@@ -525,7 +532,7 @@ int launch_fir_crcf_slide(const cf32 *win, const cf32 *x, const float *taps_pad,
     const unsigned grid = (unsigned)tiles;
     firfilt_crcf_slide_kernel<<<grid, 256, slide_lds_bytes(Lp), st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), taps_pad, L, Lp,
-        scale, reinterpret_cast<float2 *>(y), ny);
+        scale, reinterpret_cast<float2 *>(y), ny, reinterpret_cast<float2 *>(win_next));
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
