@@ -2149,7 +2149,10 @@ int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const 
     CHECK_PTR(x);
     CHECK_PTR(y);
     // a p == 1 channelizer has no history; the 1-sample placeholder window is never read
-    YG_TRY(launch_firpfbch(q->hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st));
+    bool written = false;
+    cf32 *next = (q->p > 1 && q->hist.len == (int)((q->p - 1) * q->M)) ? q->hist.next() : nullptr;
+    YG_TRY(launch_firpfbch(q->hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st, next, &written));
+    if (written) { q->hist.flip(); return YAGI_OK; }         // the kernel's last workgroup wrote the next history
     if (q->p > 1) return q->hist.advance(x, nframes * (size_t)q->M, q->st);
     return YAGI_OK;
 }
@@ -2275,9 +2278,11 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    bool written = false;
     YG_TRY(launch_firpfbch2(q->hist.dev(), q->hist.len, x, q->h.as<float>(), q->M, q->m, q->tw.as<cf32>(),
-                            q->step, rank, nranks, y, nsteps, q->st));
+                            q->step, rank, nranks, y, nsteps, q->st, q->hist.next(), &written));
     q->step += nsteps;
+    if (written) { q->hist.flip(); return YAGI_OK; }         // the kernel's last workgroup wrote the next history
     return q->hist.advance(x, nsteps * (size_t)(q->M / 2), q->st);
 }
 int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {

@@ -163,6 +163,18 @@ firpfbch_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
 // outputs go to LDS once, the workgroup runs the M-point register-butterfly passes over all 256/M*16
 // transforms together and stores [frame][channel] fully coalesced.
 // HBM traffic: 8 B/sample in (+ (p-1)/run halo, L2-served between the groups of one workgroup) + 8 out.
+// History after the block = last hist_len samples of (hist ++ x[0..n_in)), written by the LAST workgroup of the
+// analyzer kernel itself into the object's other history buffer (saves the separate 4-5 us update launch).
+__device__ __forceinline__ void chan_write_next_hist(const float2 *__restrict__ hist, int hist_len,
+                                                     const float2 *__restrict__ x, size_t n_in,
+                                                     float2 *__restrict__ hist_next) {
+    if (hist_next == nullptr || blockIdx.x != gridDim.x - 1) return;
+    for (int j = threadIdx.x; j < hist_len; j += blockDim.x) {
+        const size_t c = n_in + (size_t)j;
+        hist_next[j] = (c < (size_t)hist_len) ? hist[c] : x[c - (size_t)hist_len];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS slot pitch of one transform in the column kernels: M + 32/nq for nq <= 32 transforms in flight
 // (fft_radix.hpp), M + 1 (odd: the lanes of a pass, one transform apart, cover all banks) beyond
@@ -179,8 +191,9 @@ template <int P, int LGM>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                     const float *__restrict__ h, const float2 *__restrict__ twM,
-                    float2 *__restrict__ y, size_t nframes, int run) {
+                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next) {
     constexpr int M = 1 << LGM, lgM = LGM;
+    chan_write_next_hist(hist, (P - 1) * M, x, nframes * (size_t)M, hist_next);
     // 8, 16: one pass; 32 = 8 x 4, 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -269,7 +282,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
 
 template <int P, int LGM>
 static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
-                               cf32 *y, size_t nframes, hipStream_t st) {
+                               cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
@@ -292,7 +305,8 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     firpfbch_col_kernel<P, LGM><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
                                                        reinterpret_cast<const float2 *>(x), h,
                                                        reinterpret_cast<const float2 *>(twM),
-                                                       reinterpret_cast<float2 *>(y), nframes, (int)run);
+                                                       reinterpret_cast<float2 *>(y), nframes, (int)run,
+                                                       reinterpret_cast<float2 *>(hist_next));
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -416,7 +430,8 @@ static constexpr size_t kChanLdsBudget = 38 * 1024;   // <= 4 workgroups per CU
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
-                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st) {
+                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next, bool *hist_written) {
+    if (hist_written) *hist_written = false;
     if (nframes == 0) return YAGI_OK;
     if ((M == 512 || M == 1024) && (p == 4 || p == 8) && nframes >= 64) {
         if (M == 512) return p == 4 ? launch_firpfbch_wide<4, 9>(hist, x, h, twM, y, nframes, st)
@@ -427,12 +442,13 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
     if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && nframes >= 64) {
 #define YG_COL_CASE(PP)                                                                              \
     case PP:                                                                                         \
-        return M == 8 ? launch_firpfbch_col<PP, 3>(hist, x, h, twM, y, nframes, st)                  \
-             : M == 16 ? launch_firpfbch_col<PP, 4>(hist, x, h, twM, y, nframes, st)                 \
-             : M == 32 ? launch_firpfbch_col<PP, 5>(hist, x, h, twM, y, nframes, st)                 \
-             : M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st)                 \
-             : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st)                \
-                        : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st);
+        if (hist_written) *hist_written = hist_next != nullptr;                                      \
+        return M == 8 ? launch_firpfbch_col<PP, 3>(hist, x, h, twM, y, nframes, st, hist_next)                  \
+             : M == 16 ? launch_firpfbch_col<PP, 4>(hist, x, h, twM, y, nframes, st, hist_next)                 \
+             : M == 32 ? launch_firpfbch_col<PP, 5>(hist, x, h, twM, y, nframes, st, hist_next)                 \
+             : M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st, hist_next)                 \
+             : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st, hist_next)                \
+                        : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st, hist_next);
         switch (p) {
             YG_COL_CASE(4)
             YG_COL_CASE(8)
@@ -754,9 +770,11 @@ template <int P, int LGM, bool SHARDED>
 __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM, Pow2Plan plan,
-                     int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */) {
+                     int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */,
+                     float2 *__restrict__ hist_next) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
+    chan_write_next_hist(hist, hist_len, x, nsteps * (size_t)M2, hist_next);
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;   // 8, 16: one pass; 32 = 8 x 4
     constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;       // transforms in flight (kColHalf = 8)
     constexpr int pitch = col_pitch(M, nq);
@@ -877,7 +895,8 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 
 template <int P, int LGM>
 static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, const float *h,
-                                const cf32 *twM, int rank, int nranks, cf32 *y, size_t nsteps, hipStream_t st) {
+                                const cf32 *twM, int rank, int nranks, cf32 *y, size_t nsteps, hipStream_t st,
+                                cf32 *hist_next) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     size_t run = nsteps / ((size_t)YG_COL_WGS * G);
@@ -894,10 +913,11 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     float2 *fy = reinterpret_cast<float2 *>(y);
     if (nranks > 1)
         firpfbch2_col_kernel<P, LGM, true><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, make_pow2_plan(M / nranks),
-                                                                  rank, nranks, fy, nsteps, (int)run);
+                                                                  rank, nranks, fy, nsteps, (int)run,
+                                                                  reinterpret_cast<float2 *>(hist_next));
     else
         firpfbch2_col_kernel<P, LGM, false><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, Pow2Plan{0, {0}}, 0, 1,
-                                                                   fy, nsteps, (int)run);
+                                                                   fy, nsteps, (int)run, reinterpret_cast<float2 *>(hist_next));
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -1041,7 +1061,8 @@ static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, 
 
 int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
                      const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
-                     hipStream_t st) {
+                     hipStream_t st, cf32 *hist_next, bool *hist_written) {
+    if (hist_written) *hist_written = false;
     if (nsteps == 0) return YAGI_OK;
     const int p = 2 * m, M2 = M / 2;
     if (nranks < 1 || M % nranks || rank < 0 || rank >= nranks)
@@ -1061,12 +1082,13 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
         is_pow2(M / nranks)) {
 #define YG_COL2_CASE(PP)                                                                                          \
     case PP:                                                                                                      \
-        return M == 8 ? launch_firpfbch2_col<PP, 3>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)       \
-             : M == 16 ? launch_firpfbch2_col<PP, 4>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
-             : M == 32 ? launch_firpfbch2_col<PP, 5>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
-             : M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)      \
-             : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st)     \
-                        : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st);
+        if (hist_written) *hist_written = hist_next != nullptr;                                                   \
+        return M == 8 ? launch_firpfbch2_col<PP, 3>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)       \
+             : M == 16 ? launch_firpfbch2_col<PP, 4>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
+             : M == 32 ? launch_firpfbch2_col<PP, 5>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
+             : M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
+             : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)     \
+                        : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next);
         switch (p) {
             YG_COL2_CASE(2)
             YG_COL2_CASE(4)

@@ -146,8 +146,11 @@ int launch_spgram_psd(const float *psd, int nfft, float scale, bool in_db, float
 
 // ---- chan_kernels.hip ----------------------------------------------------------------------
 // firpfbch analyzer: hist = the (p-1)*M samples preceding x[0] (oldest first).
+// hist_next (optional): the object's other history buffer; when the kernel taken can write the history after the
+// block itself, *hist_written is set and the caller skips its own update.
 int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
-                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st);
+                    const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next = nullptr,
+                    bool *hist_written = nullptr);
 // firpfbch synthesizer: x = nframes frames of M channel samples, hist = the (p-1)*M channel samples before them;
 // y[f*M + i] = sum_n h[i + n*M] * IDFT_M(frame f-n)[i]
 int launch_firpfbch_syn(const cf32 *hist, const cf32 *x, const float *h, int M, int p,
@@ -160,7 +163,7 @@ int launch_firpfbch2_syn(const cf32 *hist, int hist_len, const cf32 *x, const fl
 // first step (parity selects the half rotation).  rank/nranks select sub-bands k = rank + nranks*q.
 int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
                      const cf32 *twM, uint64_t step0, int rank, int nranks, cf32 *y, size_t nsteps,
-                     hipStream_t st);
+                     hipStream_t st, cf32 *hist_next = nullptr, bool *hist_written = nullptr);
 int launch_firpfbch2_assemble(const cf32 *gathered, size_t nsteps, int M, int nranks, cf32 *y,
                               hipStream_t st);
 
