@@ -1219,9 +1219,11 @@ struct FirInterp {
     // n inputs -> n*interp outputs (device pointers)
     int block_dev(const T *x, size_t n, T *y) {
         YG_TRY(bank.w.flush(bank.st));
+        if (n == 0) return YAGI_OK;
         YG_TRY((launch_firpfb_all<K>(bank.w.dev(), x, bank.taps.template as<C>(), bank.nf, bank.Ls,
-                                     bank.scale, y, n, bank.st)));
-        return bank.w.advance(x, n, bank.st);
+                                     bank.scale, y, n, bank.st, bank.w.next())));
+        bank.w.flip();                              // the kernel's last workgroup wrote the next window
+        return YAGI_OK;
     }
     int block_host(const T *x, size_t n, T *y) {
         if (n == 0) return YAGI_OK;
@@ -1405,9 +1407,11 @@ struct RresampObj {
     // nblocks primitive blocks: nblocks*Q inputs -> nblocks*P outputs (device pointers); :162-183
     int blocks_dev(const T *x, size_t nblocks, T *y) {
         YG_TRY(bank.w.flush(bank.st));
+        if (nblocks == 0) return YAGI_OK;
         YG_TRY((launch_rresamp<K>(bank.w.dev(), x, bank.taps.template as<C>(), P, Q, bank.Ls, bank.scale, y,
-                                  nblocks, bank.st)));
-        return bank.w.advance(x, nblocks * (size_t)Q, bank.st);
+                                  nblocks, bank.st, bank.w.next())));
+        bank.w.flip();                              // the kernel's last workgroup wrote the next window
+        return YAGI_OK;
     }
     int blocks_host(const T *x, size_t nblocks, T *y) {
         if (nblocks == 0) return YAGI_OK;

@@ -443,11 +443,12 @@ template <class K, bool TAPS_LDS>
 __global__ void __launch_bounds__(256)
 firpfb_all_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                   const typename K::C *__restrict__ hb, int nf, int Ls, typename K::C scale,
-                  typename K::T *__restrict__ y, size_t n) {
+                  typename K::T *__restrict__ y, size_t n, typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);                       // kPfbTN + Ls - 1 samples
+    write_next_window(win, x, n, Ls, win_next);
     C *hsT = reinterpret_cast<C *>(smem + ((size_t)(kPfbTN + Ls - 1) * sizeof(T) + 15) / 16 * 16);
     const size_t n0 = (size_t)blockIdx.x * kPfbTN;
     const int nt = (int)((n - n0) < (size_t)kPfbTN ? (n - n0) : (size_t)kPfbTN);
@@ -480,11 +481,12 @@ template <class K>
 __global__ void __launch_bounds__(256)
 firpfb_fewbranch_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                         const typename K::C *__restrict__ hb, int nf, int Ls, typename K::C scale,
-                        typename K::T *__restrict__ y, size_t n) {
+                        typename K::T *__restrict__ y, size_t n, typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);                       // 256 + Ls - 1 samples
+    write_next_window(win, x, n, Ls, win_next);
     const size_t n0 = (size_t)blockIdx.x * 256;
     const int nt = (int)((n - n0) < (size_t)256 ? (n - n0) : (size_t)256);
     const long long base = (long long)n0 - (Ls - 1);
@@ -519,7 +521,8 @@ firpfb_fewbranch_kernel(const typename K::T *__restrict__ win, const typename K:
 
 template <class K>
 int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
-                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st) {
+                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st,
+                      typename K::T *win_next) {
     using T = typename K::T;
     using C = typename K::C;
     if (n == 0) return YAGI_OK;
@@ -527,7 +530,7 @@ int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const ty
         const size_t nblk = (n + 255) / 256;
         if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
         firpfb_fewbranch_kernel<K><<<(unsigned)nblk, 256, (size_t)(256 + Ls - 1) * sizeof(T), st>>>(win, x, hb, nf, Ls,
-                                                                                                   scale, y, n);
+                                                                                                   scale, y, n, win_next);
         YG_LAUNCH_CHECK();
         return YAGI_OK;
     }
@@ -538,15 +541,15 @@ int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const ty
     const size_t nblk = (n + kPfbTN - 1) / kPfbTN;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     if (taps_lds)
-        firpfb_all_kernel<K, true><<<(unsigned)nblk, 256, xs_bytes + tap_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n);
+        firpfb_all_kernel<K, true><<<(unsigned)nblk, 256, xs_bytes + tap_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n, win_next);
     else
-        firpfb_all_kernel<K, false><<<(unsigned)nblk, 256, xs_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n);
+        firpfb_all_kernel<K, false><<<(unsigned)nblk, 256, xs_bytes, st>>>(win, x, hb, nf, Ls, scale, y, n, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
-template int launch_firpfb_all<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t);
-template int launch_firpfb_all<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t);
-template int launch_firpfb_all<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t);
+template int launch_firpfb_all<RRRF>(const float *, const float *, const float *, int, int, float, float *, size_t, hipStream_t, float *);
+template int launch_firpfb_all<CRCF>(const cf32 *, const cf32 *, const float *, int, int, float, cf32 *, size_t, hipStream_t, cf32 *);
+template int launch_firpfb_all<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, cf32, cf32 *, size_t, hipStream_t, cf32 *);
 
 // ---------------------------------------------------------------------------------------------
 // branch index per sample (the arbitrary resampler's access pattern, resamp.rs:141-154 with the
@@ -608,11 +611,12 @@ template <class K>
 __global__ void __launch_bounds__(256)
 rresamp_kernel(const typename K::T *__restrict__ win, const typename K::T *__restrict__ x,
                const typename K::C *__restrict__ hb, int P, int Q, int Ls, typename K::C scale,
-               typename K::T *__restrict__ y, size_t nblocks, int tile_blocks) {
+               typename K::T *__restrict__ y, size_t nblocks, int tile_blocks, typename K::T *__restrict__ win_next) {
     using T = typename K::T;
     using C = typename K::C;
     extern __shared__ __align__(16) unsigned char smem[];
     T *xs = reinterpret_cast<T *>(smem);
+    write_next_window(win, x, nblocks * (size_t)Q, Ls, win_next);
     const size_t b0 = (size_t)blockIdx.x * tile_blocks;
     const int nb = (int)((nblocks - b0) < (size_t)tile_blocks ? (nblocks - b0) : (size_t)tile_blocks);
     const long long base = (long long)b0 * Q - (Ls - 1);
@@ -633,7 +637,8 @@ rresamp_kernel(const typename K::T *__restrict__ win, const typename K::T *__res
 
 template <class K>
 int launch_rresamp(const typename K::T *win, const typename K::T *x, const typename K::C *hb, int P, int Q,
-                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st) {
+                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st,
+                   typename K::T *win_next) {
     using T = typename K::T;
     if (nblocks == 0) return YAGI_OK;
     // blocks per tile: ~1024 outputs or inputs, whichever is larger, inside the LDS budget
@@ -645,12 +650,12 @@ int launch_rresamp(const typename K::T *win, const typename K::T *x, const typen
     if (bytes(tb) > kFirLdsBudget) return fail(YAGI_ERR_CONFIG, "rresamp: Q and the branch length do not fit the LDS (%d, %d)", Q, Ls);
     const size_t nblk = (nblocks + tb - 1) / tb;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    rresamp_kernel<K><<<(unsigned)nblk, 256, bytes(tb), st>>>(win, x, hb, P, Q, Ls, scale, y, nblocks, tb);
+    rresamp_kernel<K><<<(unsigned)nblk, 256, bytes(tb), st>>>(win, x, hb, P, Q, Ls, scale, y, nblocks, tb, win_next);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
-template int launch_rresamp<RRRF>(const float *, const float *, const float *, int, int, int, float, float *, size_t, hipStream_t);
-template int launch_rresamp<CRCF>(const cf32 *, const cf32 *, const float *, int, int, int, float, cf32 *, size_t, hipStream_t);
-template int launch_rresamp<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, int, cf32, cf32 *, size_t, hipStream_t);
+template int launch_rresamp<RRRF>(const float *, const float *, const float *, int, int, int, float, float *, size_t, hipStream_t, float *);
+template int launch_rresamp<CRCF>(const cf32 *, const cf32 *, const float *, int, int, int, float, cf32 *, size_t, hipStream_t, cf32 *);
+template int launch_rresamp<CCCF>(const cf32 *, const cf32 *, const cf32 *, int, int, int, cf32, cf32 *, size_t, hipStream_t, cf32 *);
 
 }  // namespace yagi

@@ -40,7 +40,8 @@ int launch_fir_block(const typename K::T *win, const typename K::T *x, const typ
 // branch taps hb laid out [nf][Ls] in natural (newest-first) order.
 template <class K>
 int launch_firpfb_all(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
-                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st);
+                      int nf, int Ls, typename K::C scale, typename K::T *y, size_t n, hipStream_t st,
+                      typename K::T *win_next = nullptr /* see launch_fir_block */);
 // branch chosen per sample: y[n] = scale * sum_k hb[idx[n]][k] X[n-k]
 template <class K>
 int launch_firpfb_select(const typename K::T *win, const typename K::T *x, const typename K::C *hb,
@@ -50,7 +51,8 @@ int launch_firpfb_select(const typename K::T *win, const typename K::T *x, const
 // Rresamp: y[blk*P + n] = scale * sum_k hb[(n*Q) % P][k] X[blk*Q + (n*Q)/P - k], n < P, blk < nblocks
 template <class K>
 int launch_rresamp(const typename K::T *win, const typename K::T *x, const typename K::C *hb, int P, int Q,
-                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st);
+                   int Ls, typename K::C scale, typename K::T *y, size_t nblocks, hipStream_t st,
+                   typename K::T *win_next = nullptr /* see launch_fir_block */);
 
 // ---- stream_kernels.hip (crcf M=1 hot case; headline fused FIR -> 4096-pt FFT) -----------------
 // taps_pad = h zero-padded to Lp = roundup(L, 32) floats.
