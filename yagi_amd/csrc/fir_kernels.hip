@@ -133,6 +133,84 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
     }
 }
 
+// one chunk of eight samples of the rrrf body below (FULL: all eight inside d <= L-8; else wave-uniform guards)
+template <bool FULL>
+__device__ __forceinline__ void fir_consec_rrrf_chunk(v2f (&a2)[4], const float *xl, const float *__restrict__ taps,
+                                                      int L, int Lp, int c) {
+    const int d0 = 1 + 8 * c;                                // samples d0 .. d0+7 live in one pad group:
+    const float *rb = xl + 9 * ((Lp >> 3) - c - 1);          // sample d0 + u at rb[7 - u]
+    v2f g2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g2[i] = v2f{rb[2 * i], rb[2 * i + 1]};
+    float ht[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) ht[i] = taps[(FULL || d0 + i < L) ? d0 + i : L - 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int gi = 7 - u;
+        if (FULL || d0 + u <= L - 8) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const v2f hp = v2f{ht[u + 2 * p], ht[u + 2 * p + 1]};
+                if (gi & 1)
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a2[p]) : "v"(g2[gi >> 1]), "s"(hp));
+                else
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a2[p]) : "v"(g2[gi >> 1]), "s"(hp));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rrrf body of fir_consec_kernel.  Real samples would have to sit in adjacent registers in exactly the pairing a
+// packed FMA wants, and a sliding window breaks that on every other tap (the compiler patches it with one v_mov per
+// two v_pk_fma_f32).  Turned around -- outer loop over the SAMPLE, which is broadcast to both halves (op_sel), packed
+// operand = two adjacent TAPS from an SGPR pair -- no register pairing of samples is needed at all:
+//     (y[8l+2p], y[8l+2p+1]) += X[8l - d] * (h[d+2p], h[d+2p+1]),   p < 4,  d = 1 .. L-8   (all 8 taps inside h)
+// Samples come from LDS eight at a time (one pad group of the lane's row), taps through the scalar cache.  The
+// 15 edge samples (d = -7..0 and d > L-8), where only some of the lane's outputs have a tap, are two static
+// triangles of scalar FMAs.  Every output still adds its taps in the order k = 0, 1, .. L-1 with one FMA each: bit-identical
+// to fir_block_kernel, and no tap outside h is ever multiplied.  xl = lane's row (slot of sample 8l - d:
+// e + (e >> 3), e = Lp - d).  Needs L >= 16.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fir_consec_rrrf_body(const float *xl, const float *__restrict__ taps, int L, int Lp,
+                                                     float (&acc)[8]) {
+    v2f a2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) a2[p] = v2f{0.f, 0.f};
+    // head: samples X[8l + j], j = 7 .. 0 (d = -j); output r >= j takes tap h[r - j] -- a static triangle
+    {
+        const float *rb = xl + 9 * (Lp >> 3);                    // sample 8l + j at rb[j]
+        float g[8], h0[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g[j] = rb[j]; h0[j] = taps[j]; }
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+#pragma unroll
+            for (int r = j; r < 8; ++r) a2[r >> 1][r & 1] = fmaf(g[j], h0[r - j], a2[r >> 1][r & 1]);
+    }
+    // body: d = 1 .. L-8 in chunks of 8 samples (fir_consec_rrrf_chunk); the last chunk may be partial
+    const int nch = (L - 8) >> 3;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) fir_consec_rrrf_chunk<true>(a2, xl, taps, L, Lp, c);
+    if (((L - 8) & 7) != 0) fir_consec_rrrf_chunk<false>(a2, xl, taps, L, Lp, nch);
+    // tail: d = L-8+t, t = 1 .. 7; output r <= 7 - t takes tap h[L-8+t+r] -- the other static triangle
+    {
+        float hl[8];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) hl[i] = taps[L - 8 + i];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) {
+            const int e = Lp - (L - 8 + t);
+            const float xv = xl[e + (e >> 3)];
+#pragma unroll
+            for (int r = 0; r + t < 8; ++r) a2[r >> 1][r & 1] = fmaf(xv, hl[t + r], a2[r >> 1][r & 1]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = a2[r >> 1][r & 1];
+}
+
 // ---------------------------------------------------------------------------------------------
 // M = 1 direct form with register reuse (all three type combinations): a lane owns 8 CONSECUTIVE outputs and walks
 // the taps with an 8-sample register window that slides by one sample per tap -- one LDS read per 8 multiply-
@@ -197,6 +275,14 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
     // at tap k (j = Lp-1-k) output r of the lane needs span sample 8l + q with q = r + j + 1, i.e. slot
     // 9l + q + (q >> 3); it is kept in w[(r + j) & 7]
     const T *xl = xs + 9 * l;
+    bool done = false;
+    if constexpr (K::id == 0) {
+        if (L >= 16) {                                           // block-uniform
+            fir_consec_rrrf_body(xl, taps, L, Lp, acc);
+            done = true;
+        }
+    }
+    if (!done) {
     {
         const int j = Lp - 1;                                    // j & 7 == 7
 #pragma unroll
@@ -227,6 +313,7 @@ fir_consec_kernel(const typename K::T *__restrict__ win, const typename K::T *__
 #pragma unroll
         for (int u = 0; u < 8; ++u) hk[u] = taps[k0 + u < L ? k0 + u : L - 1];
         eight_taps(hk, k0, std::false_type{});
+    }
     }
     const int o = kConsecR * l;
     if (o + kConsecR <= nt) {
