@@ -93,3 +93,32 @@ def test_integer_inputs_are_exact(ya):
     a = rng.integers(-8, 9, 4096).astype(np.float32)
     b = rng.integers(-8, 9, 4096).astype(np.float32)
     assert ya.dotprod(a, b) == np.float32(np.dot(a.astype(np.int64), b.astype(np.int64)))
+
+
+@pytest.mark.parametrize("name,ta,tb", [("rrrf", np.float32, np.float32), ("crcf", np.complex64, np.float32),
+                                        ("cccf", np.complex64, np.complex64)])
+def test_device_pointers_of_any_alignment(ya, name, ta, tb):
+    """*_dev entry points on device-resident operands: the 16-byte-load path (operands on 16-byte boundaries) and the
+    element-wise path (operands offset by one element) must agree with each other to rounding and with the f64 sum;
+    odd lengths leave a tail for the scalar loop."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 3 * 256 * 64 + 1237
+
+    def rnd(t, m):
+        v = rng.standard_normal(m)
+        return (v + 1j * rng.standard_normal(m)).astype(t) if t == np.complex64 else v.astype(t)
+
+    a, b = rnd(ta, n + 1), rnd(tb, n + 1)
+    da, db = ya.DeviceArray.from_numpy(a), ya.DeviceArray.from_numpy(b)
+    ty = np.float32 if name == "rrrf" else np.complex64
+    dy = ya.DeviceArray(2, ty)
+    fn = getattr(ya.lib, f"yagi_hip_dotprod_{name}_dev")
+    got = []
+    for off in (0, 1):
+        pa, pb = da.ptr + off * a.itemsize, db.ptr + off * b.itemsize
+        assert fn(C.c_void_p(pa), C.c_void_p(pb), n, C.c_void_p(dy.ptr), None) == 0
+        ya.synchronize()
+        got.append(dy.to_numpy(1)[0])
+        want = np.sum(a[off:off + n].astype(np.complex128) * b[off:off + n].astype(np.complex128))
+        assert abs(complex(got[-1]) - want) <= 4e-5 * np.sqrt(n)
