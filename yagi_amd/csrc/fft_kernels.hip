@@ -115,7 +115,7 @@ fft_mixed_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict
     const int total = nb * N;
     const float2 *gsrc = in + b0 * N;
     float2 *gdst = out + b0 * N;
-    for (int e = threadIdx.x; e < total; e += 256) bufA[e] = gsrc[e];
+    batched_for<256>(total, [&](int e) { return gsrc[e]; }, [&](int e, float2 v) { bufA[e] = v; });
     __syncthreads();
     float2 *src = bufA, *dst = bufB;
     int Ns = 1;
@@ -135,7 +135,7 @@ fft_mixed_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict
         float2 *tmp = src; src = dst; dst = tmp;
         Ns *= R;
     }
-    for (int e = threadIdx.x; e < total; e += 256) gdst[e] = src[e];
+    batched_for<256>(total, [&](int e) { return src[e]; }, [&](int e, float2 v) { gdst[e] = v; });
 }
 
 // Power-of-two N <= 8192 (other than 4096): a workgroup owns `nfr` consecutive transforms (so small
@@ -166,10 +166,13 @@ fft_pow2_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *__r
     const int total = nb * N;
     const float2 *src = in + b0 * N;
     float2 *dst = out + b0 * N;
-    for (int e = threadIdx.x; e < total; e += 256) bufA[(e >> lgN) * pitch + (e & (N - 1))] = src[e];
+    // global <-> LDS copies with the loads batched (devmath.hpp: batched_for)
+    batched_for<256>(total, [&](int e) { return src[e]; },
+                     [&](int e, float2 v) { bufA[(e >> lgN) * pitch + (e & (N - 1))] = v; });
     __syncthreads();
     const float2 *res = lds_fft_pow2<SIGN, FRFAST>(bufA, bufB, N, FRFAST ? nfr : nb, plan, twl, 1, false, pitch, lgnfr);
-    for (int e = threadIdx.x; e < total; e += 256) dst[e] = res[(e >> lgN) * pitch + (e & (N - 1))];
+    batched_for<256>(total, [&](int e) { return res[(e >> lgN) * pitch + (e & (N - 1))]; },
+                     [&](int e, float2 v) { dst[e] = v; });
 }
 
 // Bluestein element-wise stages: a[k] = x[k] w[k] zero-padded to m;  X[k] = w[k] y[k] / m
@@ -268,21 +271,36 @@ fft_twopass_kernel(int N, Pow2Plan plan, const float2 *__restrict__ in, float2 *
     float2 *dst = out + blockIdx.y * n;
     const int t0 = blockIdx.x * nfr;                             // first column (pass 0) / row (pass 1) of the tile
     const int lgN = 31 - __builtin_clz((unsigned)N);
-    const int total = nfr * N;
+    // nfr * N = 2048 points: the eight loads of a lane are all issued before the first LDS write
+    float2 r[8];
     if (MODE == 0) {
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int tr = e & (nfr - 1), p = e >> lgnfr;
-            bufA[tr * pitch + p] = src[(size_t)p * n2 + t0 + tr];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + 256 * it, tr = e & (nfr - 1), p = e >> lgnfr;
+            r[it] = src[(size_t)p * n2 + t0 + tr];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + 256 * it, tr = e & (nfr - 1), p = e >> lgnfr;
+            bufA[tr * pitch + p] = r[it];
         }
     } else {
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int tr = e >> lgN, p = e & (N - 1);
-            bufA[tr * pitch + p] = src[(size_t)(t0 + tr) * n2 + p];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + 256 * it, tr = e >> lgN, p = e & (N - 1);
+            r[it] = src[(size_t)(t0 + tr) * n2 + p];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + 256 * it, tr = e >> lgN, p = e & (N - 1);
+            bufA[tr * pitch + p] = r[it];
         }
     }
     __syncthreads();
     const float2 *res = lds_fft_pow2<SIGN, true>(bufA, bufB, N, nfr, plan, twl, 1, false, pitch, lgnfr);
-    for (int e = threadIdx.x; e < total; e += 256) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = threadIdx.x + 256 * it;
         const int tr = e & (nfr - 1), k = e >> lgnfr;
         float2 v = res[tr * pitch + k];
         if (MODE == 0) {
