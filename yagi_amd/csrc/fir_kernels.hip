@@ -69,21 +69,22 @@ fir_block_kernel(const typename K::T *__restrict__ win, const typename K::T *__r
 
     T *xs = reinterpret_cast<T *>(smem);
     if (STAGE) {
+        // loads issued in batches before the LDS writes (devmath.hpp: batched_for)
         if (base >= 0 && base + span <= x_len) {       // block-uniform: the whole span lies inside x
             const T *src = x + base;
             if (M == 1) {
-                for (int i = threadIdx.x; i < span; i += kFirBlock) xs[i] = src[i];
+                batched_for<kFirBlock>(span, [&](int i) { return src[i]; }, [&](int i, T v) { xs[i] = v; });
             } else {
-                for (int i = threadIdx.x; i < span; i += kFirBlock) {
+                batched_for<kFirBlock>(span, [&](int i) { return src[i]; }, [&](int i, T v) {
                     const int j = i / M, ph = i - j * M;
-                    xs[ph * pitch + j] = src[i];
-                }
+                    xs[ph * pitch + j] = v;
+                });
             }
         } else {
-            for (int i = threadIdx.x; i < span; i += kFirBlock) {
+            batched_for<kFirBlock>(span, [&](int i) { return load_stream(win, x, base + i, L); }, [&](int i, T v) {
                 const int j = i / M, ph = i - j * M;
-                xs[ph * pitch + j] = load_stream(win, x, base + i, L);
-            }
+                xs[ph * pitch + j] = v;
+            });
         }
         __syncthreads();
     }
@@ -370,20 +371,23 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
     // entry e = jj*M + ph; (jj, ph) advance by NT entries per trip without a division
     const int djj = NT / M, dph = NT - djj * M;
     int jj = (int)threadIdx.x / M, ph = (int)threadIdx.x - jj * M;
-    if (base >= 0 && base + total <= xlen) {                     // block-uniform: every entry lies inside x
-        const T *src = x + base;
-        for (int e = threadIdx.x; e < total; e += NT) {
-            xs[ph * pitch + jj + (jj >> LG)] = src[e];
-            jj += djj; ph += dph;
-            if (ph >= M) { ph -= M; ++jj; }
-        }
-    } else {
-        for (int e = threadIdx.x; e < total; e += NT) {
-            const long long idx = base + e;
+    // eight loads per lane in flight before the LDS writes; (jj, ph) advance with the stores, in order
+    const bool inside = base >= 0 && base + total <= xlen;       // block-uniform: every entry lies inside x
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * NT) {
+        T r[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = e0 + NT * it;
+            const long long idx = base + (e < total ? e : total - 1);
             T v = zero_of<T>();
-            if (idx < 0) v = win[L + idx];
+            if (inside) v = x[idx];
+            else if (idx < 0) v = win[L + idx];
             else if (idx < xlen) v = x[idx];
-            xs[ph * pitch + jj + (jj >> LG)] = v;
+            r[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (e0 + NT * it < total) xs[ph * pitch + jj + (jj >> LG)] = r[it];
             jj += djj; ph += dph;
             if (ph >= M) { ph -= M; ++jj; }
         }
@@ -577,7 +581,7 @@ firpfb_fewbranch_kernel(const typename K::T *__restrict__ win, const typename K:
     const size_t n0 = (size_t)blockIdx.x * 256;
     const int nt = (int)((n - n0) < (size_t)256 ? (n - n0) : (size_t)256);
     const long long base = (long long)n0 - (Ls - 1);
-    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    batched_for<256>(nt + Ls - 1, [&](int i) { return load_stream(win, x, base + i, Ls); }, [&](int i, T v) { xs[i] = v; });
     __syncthreads();
     const int nl = threadIdx.x;
     if (nl >= nt) return;
@@ -708,7 +712,7 @@ rresamp_kernel(const typename K::T *__restrict__ win, const typename K::T *__res
     const int nb = (int)((nblocks - b0) < (size_t)tile_blocks ? (nblocks - b0) : (size_t)tile_blocks);
     const long long base = (long long)b0 * Q - (Ls - 1);
     const int span = nb * Q + Ls - 1;
-    for (int i = threadIdx.x; i < span; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    batched_for<256>(span, [&](int i) { return load_stream(win, x, base + i, Ls); }, [&](int i, T v) { xs[i] = v; });
     __syncthreads();
     const int nout = nb * P;
     for (int o = threadIdx.x; o < nout; o += 256) {
