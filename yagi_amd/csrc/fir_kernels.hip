@@ -544,7 +544,7 @@ firpfb_all_kernel(const typename K::T *__restrict__ win, const typename K::T *__
     const size_t n0 = (size_t)blockIdx.x * kPfbTN;
     const int nt = (int)((n - n0) < (size_t)kPfbTN ? (n - n0) : (size_t)kPfbTN);
     const long long base = (long long)n0 - (Ls - 1);
-    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    batched_for<256>(nt + Ls - 1, [&](int i) { return load_stream(win, x, base + i, Ls); }, [&](int i, T v) { xs[i] = v; });
     if (TAPS_LDS)
         for (int e = threadIdx.x; e < nf * Ls; e += 256) {
             const int i = e / Ls, k = e - i * Ls;
@@ -661,7 +661,7 @@ firpfb_select_kernel(const typename K::T *__restrict__ win, const typename K::T 
     const size_t n0 = (size_t)blockIdx.x * kSelTile;
     const int nt = (int)((n - n0) < (size_t)kSelTile ? (n - n0) : (size_t)kSelTile);
     const long long base = (long long)n0 - (Ls - 1);
-    for (int i = threadIdx.x; i < nt + Ls - 1; i += 256) xs[i] = load_stream(win, x, base + i, Ls);
+    batched_for<256>(nt + Ls - 1, [&](int i) { return load_stream(win, x, base + i, Ls); }, [&](int i, T v) { xs[i] = v; });
     __syncthreads();
     for (int nl = threadIdx.x; nl < nt; nl += 256) {
         uint32_t b = idx[n0 + nl];
