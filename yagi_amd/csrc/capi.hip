@@ -145,6 +145,9 @@ struct FirFilt {
     int Lm = 0;                // padded length of the MFMA form (0 = not available)
     DevBuf hfreq, twf, twb;    // crcf only, L <= 2049: FFT_4096{[h;0]} and both twiddle tables (fast convolution)
     DevBuf gcorr;              // crcf only, L <= 257: reversed taps of the frame-boundary correction (firfft variant 4)
+    DevBuf hfreq_s;            // scale * hfreq for the frequency-domain stream kernel, rebuilt when the scale changes
+    bool hfreq_s_valid = false;
+    float hfreq_s_scale = 0.f;
     bool conv_ready = false;
     DevWindow<T> w;
     Workspace ws;
@@ -159,6 +162,7 @@ struct FirFilt {
         YG_TRY(taps.alloc(n * sizeof(C)));
         YG_TRY(upload(taps.p, h.data(), n * sizeof(C), st));
         conv_ready = false;
+        hfreq_s_valid = false;
         if (K::id == 1) {
             Lp = (L + 31) / 32 * 32;
             std::vector<float> hp((size_t)Lp, 0.0f);
@@ -353,6 +357,25 @@ static int make_twiddles(int n, int dir, DevBuf &buf, bool half_too = false) {
         }
     YG_TRY(buf.alloc(t.size() * sizeof(cf32)));
     return upload(buf.p, t.data(), t.size() * sizeof(cf32), nullptr);
+}
+
+// twiddle table of the 4096-point stream kernels: W_4096^m (m < 4096, forward) followed by six 256-entry rows the
+// frequency-domain kernel reads with the lane index (coalesced, no gathers): rows 0-3 W^{t 2^k}, row 4 W^{(t&15)(t>>4)},
+// row 5 W_256^{(t&15)(t>>4)}
+static int make_stream_twiddles(DevBuf &buf) {
+    std::vector<cf32> tab(4096 + 6 * 256);
+    auto W = [](unsigned m) {
+        const double a = -2.0 * M_PI * (double)(m & 4095u) / 4096.0;
+        return cf32{(float)std::cos(a), (float)std::sin(a)};
+    };
+    for (unsigned m = 0; m < 4096; ++m) tab[m] = W(m);
+    for (unsigned t = 0; t < 256; ++t) {
+        for (unsigned k = 0; k < 4; ++k) tab[4096 + 256 * k + t] = W(t << k);
+        tab[4096 + 1024 + t] = W((t & 15u) * (t >> 4));
+        tab[4096 + 1280 + t] = W(16u * (((t & 15u) * (t >> 4)) & 255u));
+    }
+    YG_TRY(buf.alloc(tab.size() * sizeof(cf32)));
+    return upload(buf.p, tab.data(), tab.size() * sizeof(cf32), nullptr);
 }
 
 static int fft_plan_init(FftPlan &p, size_t n, int dir) {
@@ -2009,7 +2032,7 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
     YG_TRY(o->fir.init(h, h_len));
     if (o->fir.L > 2049) return fail(YAGI_ERR_CONFIG, "fused stream: filter too long (%zu taps, at most 2049)", h_len);
     o->nfft = nfft;
-    if (nfft == 4096) YG_TRY(make_twiddles((int)nfft, YAGI_FFT_FORWARD, o->tw));
+    if (nfft == 4096) YG_TRY(make_stream_twiddles(o->tw));
     else YG_TRY(fft_plan_init(o->plan, nfft, YAGI_FFT_FORWARD));      // any size the Fft object supports
     *q = o.release();
     return YAGI_OK;
@@ -2058,7 +2081,13 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     if (use_freq) {
         // frequency-domain form (one kernel, 16 B/sample): FFT{h}.FFT{x_f} + FFT{frame-boundary correction}
         YG_TRY(f.prepare_conv());
-        YG_TRY(launch_firfft_crcf_4096_freq(f.w.dev(), x, f.hfreq.as<cf32>(), f.gcorr.as<float>(), f.scale, f.L,
+        if (!f.hfreq_s_valid || f.hfreq_s_scale != f.scale) {
+            YG_TRY(f.hfreq_s.ensure(4096 * sizeof(cf32)));
+            YG_TRY(launch_scale_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), 4096, f.st));
+            f.hfreq_s_valid = true;
+            f.hfreq_s_scale = f.scale;
+        }
+        YG_TRY(launch_firfft_crcf_4096_freq(f.w.dev(), x, f.hfreq_s.as<cf32>(), f.gcorr.as<float>(), f.scale, f.L,
                                             q->tw.as<cf32>(), spectra, f.w.next(), nframes, f.st));
         f.w.flip();
         return YAGI_OK;

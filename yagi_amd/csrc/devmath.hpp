@@ -66,19 +66,21 @@ __device__ __forceinline__ v2f tov(float2 a) { return v2f{a.x, a.y}; }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return f2(tov(a) + tov(b)); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return f2(tov(a) - tov(b)); }
 // a * w, w per lane
+// (both instructions in ONE asm statement: between two statements hipcc pads a wait state -- an s_nop per product,
+// ~8 % of a butterfly pass's issue slots; the hardware interlocks the dependent pair by itself)
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(tov(a)), "v"(tov(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(tov(a)), "v"(tov(w)), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(tov(a)), "v"(tov(w)));
     return f2(r);
 }
 // a * k, k wave-uniform (compile-time constants: lives in an SGPR pair)
 __device__ __forceinline__ float2 cmul_k(float2 a, float2 k) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(tov(a)), "s"(tov(k)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(tov(a)), "s"(tov(k)), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(tov(a)), "s"(tov(k)));
     return f2(r);
 }
 // a * s, s real

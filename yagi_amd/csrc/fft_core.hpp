@@ -84,6 +84,22 @@ __device__ __forceinline__ void twiddle_powers(float2 (&w)[16], const float2 *__
     w[15] = cmul(w[8], w[7]);
 }
 
+// the same from four given exact powers W^m, W^2m, W^4m, W^8m
+__device__ __forceinline__ void twiddle_powers_from(float2 (&w)[16], float2 w1, float2 w2, float2 w4, float2 w8) {
+    w[1] = w1; w[2] = w2; w[4] = w4; w[8] = w8;
+    w[3] = cmul(w[2], w[1]);
+    w[5] = cmul(w[4], w[1]);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+    w[9] = cmul(w[8], w[1]);
+    w[10] = cmul(w[8], w[2]);
+    w[11] = cmul(w[8], w[3]);
+    w[12] = cmul(w[8], w[4]);
+    w[13] = cmul(w[8], w[5]);
+    w[14] = cmul(w[8], w[6]);
+    w[15] = cmul(w[8], w[7]);
+}
+
 // Passes 1..3 of the 4096-point transform.  On entry lane b (= threadIdx.x, 0..255) holds
 // v[a] = x[256a + b].  `lds` is a kFft4096LdsFloat2 float2 buffer nobody else touches; `tw` is
 // the W_4096^m table (sign already per direction).  Output goes to out[k], k in [0,4096).
@@ -193,47 +209,6 @@ __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *
     }
     __syncthreads();
     fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
-}
-
-// Transform of a sequence that is zero from sample 256 on.  The first 16-point butterfly degenerates to
-// Z_c[b] = W4096^{bc} x[b], so pass 1 and its whole exchange are skipped: the 256 samples xs[0..256) sit in LDS
-// OUTSIDE the exchange buffer `lds` (written by the caller, a barrier ago), and the pass-2 lane (c, b') rebuilds
-// its inputs
-//     Z_c[16a + b'] = x[16a + b'] (W^{16c})^a W^{b'c}
-// from the power table of W^{16c} (4 exact loads + products); the factor W^{b'c}, common to all 16 inputs, is
-// applied to the butterfly's outputs together with the pass-2 twiddle.  Output layout as fft4096_passes_to_regs.
-// One barrier (after the exchange-2 writes); `lds` must be free on entry and is NOT released by a trailing barrier.
-template <int SIGN>
-__device__ __forceinline__ void fft4096_head256_to_regs(const float2 *__restrict__ xs, float2 (&v)[16],
-                                                        float2 *__restrict__ lds, const float2 *__restrict__ tw) {
-    const unsigned t = threadIdx.x;
-    const unsigned c = t >> 4, bp = t & 15;
-    {
-        float2 wa[16];
-        twiddle_powers(wa, tw, 16 * c, 4095u);                   // W^{16 c a}, a = 1..15: 16 c a <= 3600
-        v[0] = xs[bp];
-#pragma unroll
-        for (int a = 1; a < 16; ++a) v[a] = cmul(xs[16 * a + bp], wa[a]);
-    }
-    dft16<SIGN>(v);
-    {
-        float2 wt[16];
-        twiddle_powers(wt, tw, 16 * bp, 4095u);                  // pass-2 twiddles W^{16 b' c'}
-        const float2 wbc = tw[bp * c];                            // W^{b' c}
-#pragma unroll
-        for (int cp = 0; cp < 16; ++cp) {
-            float2 u = cmul(v[dft16_pos(cp)], wbc);
-            if (cp) u = cmul(u, wt[cp]);
-            lds[bp * kEx2Stride + cp * 16 + c] = u;
-        }
-    }
-    __syncthreads();
-    float2 w[16];
-#pragma unroll
-    for (int b = 0; b < 16; ++b) w[b] = lds[b * kEx2Stride + t];
-    dft16<SIGN>(w);
-#pragma unroll
-    for (int d = 0; d < 16; ++d) v[d] = w[dft16_pos(d)];
 }
 
 }  // namespace yagi

@@ -557,151 +557,4 @@ int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pa
     return YAGI_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// firfilt_crcf -> 4096-point FFT per frame, filtered in the frequency domain (one launch, 16 B/sample).
-//
-// Frame f of the filtered stream is y_f[n] = sum_k h[k] X[4096 f + n - k] (n < 4096, k < L, X = stream).
-// Splitting off the terms that reach back into the previous frame:
-//     y_f = h (*) x_f  +  c_f              ((*) = 4096-point circular convolution, x_f = frame f of X)
-//     c_f[n] = sum_{k > n} h[k] (X[4096 f + n - k] - x_f[4096 + n - k]),   n < L-1,  zero elsewhere
-// so, the FFT being linear,
-//     FFT{y_f} = FFT{h} . FFT{x_f} + FFT{c_f}.
-// The workgroup reads its frame once, transforms it, multiplies by FFT{h} (precomputed by prepare_conv),
-// and adds the transform of the (L-1)-sample correction -- whose first butterfly pass degenerates
-// because only its first 256 samples are non-zero.  No inverse transform, no intermediate stream: 1 2/3
-// FFTs per frame against 3.1 for overlap-save + FFT, and half the HBM traffic.
-//
-// c_f is a triangular Toeplitz product.  With d[m] = X[4096 f - (L-1) + m] - x_f[4096 - (L-1) + m]
-// (m < L-1, zero beyond) and g[j] = h[L-1-j] (j < L-1, zero beyond):  c_f[n] = sum_j g[j] d[n + j].
-// Wave w takes j in [64w, 64w+64) for all 256 n (4 consecutive n per lane, d sliding through registers,
-// g[j] wave-uniform -> scalar loads); the four partial sums meet in LDS.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFreqMaxTaps = 257;
-
-__global__ void __launch_bounds__(256)
-firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
-                             const float2 *__restrict__ hs, const float *__restrict__ gcorr, float scale, int L,
-                             const float2 *__restrict__ tw, float2 *__restrict__ out,
-                             float2 *__restrict__ win_next, unsigned nframes) {
-    __shared__ __attribute__((aligned(16))) float2 lds[kFft4096LdsFloat2 + 256];   // + the 256 correction samples
-    float2 *cvs = lds + kFft4096LdsFloat2;
-#ifdef YG_ABL_SAMEFRAME
-    const unsigned t = threadIdx.x, f = blockIdx.x & 15; // ablation: everything from / to L2
-#else
-    const unsigned t = threadIdx.x, f = blockIdx.x;
-#endif
-    const int Lc = L - 1;
-    const float2 *xf = x + (size_t)f * 4096;
-    // the two short loads of the correction go first: their wait must not include the 16 frame loads,
-    // which then stay in flight underneath the correction arithmetic
-    // (unconditional loads from clamped, always valid addresses; lanes >= L-1 discard them)
-    // stream samples just before the frame: previous frame, or the filter window (win[L-k] = X[-k])
-    const float2 *prev = Lc ? (f ? xf - Lc : win + 1) : xf;
-    const unsigned ti = (int)t < Lc ? t : 0u;
-    const float2 dp_ = prev[ti], dq_ = xf[4096 - (Lc ? Lc : 1) + ti];
-    __builtin_amdgcn_sched_barrier(0);               // keep them ahead of the frame loads
-    float2 v[16];
-#pragma unroll
-    for (unsigned a = 0; a < 16; ++a) v[a] = xf[256u * a + t];
-    // LDS layout of d and of the partial sums: sample m at float2 index m + 2 (m >> 2), i.e. 16 B of padding
-    // after every 4 samples.  A lane reads / writes its 4 samples as two 16-byte accesses; with lanes 32 B
-    // apart every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) would hit each bank twice (measured:
-    // SQ_LDS_BANK_CONFLICT = 51 % of the kernel's LDS cycles), at 48 B apart the 16 lanes of a group cover
-    // the 64 banks exactly once for every window position.
-    auto pidx = [](unsigned m) { return m + ((m >> 2) << 1); };
-    constexpr unsigned kDLen = 768, kPartStride = 384;            // 1.5 x (512 and 256) float2
-    {
-        lds[pidx(t)] = (int)t < Lc ? make_float2(dp_.x - dq_.x, dp_.y - dq_.y) : make_float2(0.f, 0.f);
-        lds[pidx(256 + t)] = make_float2(0.f, 0.f);
-        if (f == nframes - 1)                        // new filter window = last L samples of the call
-            for (int i = t; i < L; i += 256) win_next[i] = xf[4096 - L + i];
-    }
-    __syncthreads();
-    {
-        const unsigned w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
-        const int j0 = 64 * (int)w;
-        float2 acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = make_float2(0.f, 0.f);
-#ifdef YG_ABL_NOC
-        if (j0 < Lc && scale == 12345.f) {
-#else
-        if (j0 < Lc) {
-#endif
-            const unsigned m0 = 4 * l + j0;                      // first sample of the lane's window
-            float2 D[8];
-            {
-                const float4 *dp = reinterpret_cast<const float4 *>(lds + pidx(m0));
-                const float4 q0 = dp[0], q1 = dp[1];
-                D[0] = make_float2(q0.x, q0.y); D[1] = make_float2(q0.z, q0.w);
-                D[2] = make_float2(q1.x, q1.y); D[3] = make_float2(q1.z, q1.w);
-            }
-            const float *g = gcorr + j0;
-#pragma unroll 4
-            for (int jj = 0; jj < 64; jj += 4) {
-                const float4 *dp = reinterpret_cast<const float4 *>(lds + pidx(m0 + jj + 4));
-                const float4 q0 = dp[0], q1 = dp[1];
-                D[4] = make_float2(q0.x, q0.y); D[5] = make_float2(q0.z, q0.w);
-                D[6] = make_float2(q1.x, q1.y); D[7] = make_float2(q1.z, q1.w);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float gs = g[jj + s];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[r].x = fmaf(gs, D[s + r].x, acc[r].x);
-                        acc[r].y = fmaf(gs, D[s + r].y, acc[r].y);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) D[r] = D[4 + r];
-            }
-        }
-        float4 *cp = reinterpret_cast<float4 *>(lds + kDLen + kPartStride * w + pidx(4 * l));
-        cp[0] = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
-        cp[1] = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
-    }
-    __syncthreads();
-    {
-        // c_f[t] goes to LDS beside the exchange buffer; the barriers of the frame transform below make it visible
-        // to the pass-2 lanes of the correction transform
-        const float2 *cp = lds + kDLen + pidx(t);
-        const float2 p0 = cp[0], p1 = cp[kPartStride], p2 = cp[2 * kPartStride], p3 = cp[3 * kPartStride];
-        cvs[t] = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) * scale, ((p0.y + p1.y) + (p2.y + p3.y)) * scale);
-    }
-    __syncthreads();
-    fft4096_passes_to_regs<-1, true>(v, lds, tw);
-#pragma unroll
-    for (unsigned d = 0; d < 16; ++d) {
-        const float2 p = cmul(v[d], hs[t + 256u * d]);
-        v[d] = make_float2(p.x * scale, p.y * scale);
-    }
-    float2 u[16];
-#ifdef YG_ABL_NOHEAD
-#pragma unroll
-    for (unsigned d = 0; d < 16; ++d) u[d] = cvs[t];
-#else
-    fft4096_head256_to_regs<-1>(cvs, u, lds, tw);
-#endif
-    float2 *o = out + (size_t)f * 4096;
-#pragma unroll
-    for (unsigned d = 0; d < 16; ++d) o[t + 256u * d] = make_float2(v[d].x + u[d].x, v[d].y + u[d].y);
-}
-
-// gcorr: 256 floats, gcorr[j] = h[L-1-j] for j < L-1, zero beyond.  hs = FFT_4096{[h; 0]}, tw = forward
-// W_4096 table.  win_next receives the L-sample window after the call (last L samples of x).
-int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs, const float *gcorr, float scale,
-                                 int L, const cf32 *tw4096, cf32 *spectra, cf32 *win_next, size_t nframes,
-                                 hipStream_t st) {
-    if (nframes == 0) return YAGI_OK;
-    if (L < 1 || L > kFreqMaxTaps)
-        return fail(YAGI_ERR_CONFIG, "frequency-domain stream kernel needs 1..%d taps (got %d)", kFreqMaxTaps, L);
-    if (nframes > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    firfft_crcf_4096_freq_kernel<<<(unsigned)nframes, 256, 0, st>>>(
-        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x),
-        reinterpret_cast<const float2 *>(hs), gcorr, scale, L, reinterpret_cast<const float2 *>(tw4096),
-        reinterpret_cast<float2 *>(spectra), reinterpret_cast<float2 *>(win_next), (unsigned)nframes);
-    YG_LAUNCH_CHECK();
-    return YAGI_OK;
-}
-
 }  // namespace yagi
