@@ -492,6 +492,32 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q
 int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered_dev, size_t nsteps, size_t M,
                                          int nranks, yagi_cf32 *y_dev, yagi_stream_t s);
 
+/* ---- multi-GPU: RCCL over xGMI (one process per GPU) ------------------------------------------
+ * The reference has no distributed layer; the one exchange step of the hot path is the
+ * firpfbch2 analyzer with its output sub-bands sharded over the GPUs of a node.
+ * A communicator is created the RCCL way: ONE rank calls comm_unique_id and hands the 128 bytes to every rank by
+ * whatever the host has (MPI, a socket, torch.distributed); every rank then calls comm_create (collective) with
+ * its GPU current (yagi_hip_set_device).  RCCL is bound at first use (dlopen of librccl.so.1); without it these
+ * calls return YAGI_ERR_DEVICE and every other entry point of the library works unchanged.
+ *
+ * analyzer_execute_sharded_dev: rank r of R computes the sub-bands k = r + R q of `nsteps` steps (chunk by chunk),
+ * the chunks are all-gathered on the communicator's own stream while the object's stream runs the next chunk's
+ * kernel, and a permutation kernel assembles y[step][channel] -- identical on every rank, and identical to
+ * analyzer_execute_dev on one GPU.  nchunks = 0 picks a default (8, fewer for short blocks); nchunks < 0 forces the
+ * sharded pipeline (|nchunks| chunks) even for a one-rank communicator (tests).  x, y are device pointers; the
+ * call is asynchronous: on return the object's stream waits for the last chunk's assembly. */
+#define YAGI_HIP_COMM_ID_BYTES 128
+typedef struct yagi_hip_comm_s *yagi_hip_comm;
+int yagi_hip_comm_unique_id(unsigned char *id /* [YAGI_HIP_COMM_ID_BYTES] */);
+int yagi_hip_comm_create(const unsigned char *id, int rank, int nranks, yagi_hip_comm *comm);
+int yagi_hip_comm_destroy(yagi_hip_comm comm);
+int yagi_hip_comm_rank(yagi_hip_comm comm, int *rank, int *nranks);
+int yagi_hip_comm_all_gather_dev(yagi_hip_comm comm, const void *send_dev, void *recv_dev,
+                                 size_t bytes_per_rank, yagi_stream_t s);
+int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x_dev,
+                                                         size_t nsteps, yagi_hip_comm comm, int nchunks,
+                                                         yagi_cf32 *y_dev);
+
 /* ---- design helper exposed for hosts that want the taps (kaiser.rs:16-51) ---------------- */
 int yagi_hip_fir_design_kaiser(size_t n, float fc, float as_, float mu, float *h);
 

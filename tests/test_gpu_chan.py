@@ -204,6 +204,42 @@ def test_firpfbch2_sharded_driver_rccl_world1(ya, oracle):
         dist.destroy_process_group()
 
 
+def test_firpfbch2_sharded_c_abi_rccl_chunked(ya, oracle):
+    """the C-ABI communicator (yagi_hip_comm_*: RCCL bound by dlopen) and the chunked pipeline of
+    analyzer_execute_sharded_dev: shard kernel on the object's stream, all-gather + assemble on the communicator's
+    stream, chunk by chunk.  One GPU => a one-rank communicator with the pipeline forced (nchunks < 0): the R = 1
+    sharded kernel, ncclAllGather and the assemble kernel all run; result == the plain analyzer, state carried over
+    two calls, chunk counts that do not divide the block."""
+    from yagi_amd.dist import Comm
+    comm = Comm(Comm.unique_id(), 0, 1)
+    assert (comm.rank, comm.nranks) == (0, 1)
+    M, m = 256, 4
+    ns1, ns2 = 3 * 4096 + 640, 2 * 4096
+    x = oracle.gen_complex(SEED + 5, (ns1 + ns2) * (M // 2))
+    want = ya.FirPfbCh2.new_kaiser(M, m, 60.0).analyzer_execute(x)
+    dx = ya.DeviceArray.from_numpy(x)
+    for nch in (-3, -1, -8):
+        q = ya.FirPfbCh2.new_kaiser(M, m, 60.0)
+        y = ya.DeviceArray((ns1 + ns2) * M, np.complex64)
+        q.analyzer_execute_sharded_dev(dx, ns1, comm, y, nchunks=nch)
+        q.analyzer_execute_sharded_dev(dx.ptr + ns1 * (M // 2) * 8, ns2, comm, y.ptr + ns1 * M * 8, nchunks=nch)
+        ya.synchronize()
+        assert rel_l2(y.to_numpy().reshape(-1, M), want) <= 2e-6, nch
+    # nchunks >= 0 with one rank is the plain analyzer
+    q = ya.FirPfbCh2.new_kaiser(M, m, 60.0)
+    y = ya.DeviceArray((ns1 + ns2) * M, np.complex64)
+    q.analyzer_execute_sharded_dev(dx, ns1 + ns2, comm, y)
+    ya.synchronize()
+    assert rel_l2(y.to_numpy().reshape(-1, M), want) <= 2e-6
+    # the raw collective
+    a = ya.DeviceArray.from_numpy(np.arange(1024, dtype=np.float32))
+    b = ya.DeviceArray(1024, np.float32)
+    comm.all_gather_dev(a, b, 4096)
+    ya.synchronize()
+    assert np.array_equal(b.to_numpy(), np.arange(1024, dtype=np.float32))
+    comm.destroy()
+
+
 def test_config_c4_firpfbch_64ch_full_size(ya, oracle):
     """BASELINE config C4 at full size: M 64, m 8 (p = 16), 2^26 complex samples generated on the device (runs of
     256 frames per column group: 16 half tiles each, the prefetch path).  Sampled frames -- first frames, every

@@ -936,6 +936,12 @@ class FirPfbCh2(_Handle):
         _check(lib.yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(
             self._h, _devptr(x_dev), nsteps, rank, nranks, _devptr(yshard_dev)))
 
+    def analyzer_execute_sharded_dev(self, x_dev, nsteps, comm, y_dev, nchunks=0):
+        """sub-bands sharded over the ranks of `comm` (yagi_amd.dist.Comm): shard kernel -> RCCL all-gather ->
+        assemble, chunked so the exchange overlaps the next chunk's kernel; y_dev = [nsteps][M] on every rank"""
+        _check(lib.yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(
+            self._h, _devptr(x_dev), nsteps, comm._h, nchunks, _devptr(y_dev)))
+
     @staticmethod
     def assemble_dev(gathered_dev, nsteps, M, nranks, y_dev, stream=None):
         _check(lib.yagi_hip_firpfbch2_crcf_assemble_dev(_devptr(gathered_dev), nsteps, M, nranks, _devptr(y_dev), stream))

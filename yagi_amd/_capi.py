@@ -235,3 +235,11 @@ _sig("yagi_hip_firpfbch2_crcf_analyzer_execute", vp, vp, sz, vp)
 _sig("yagi_hip_firpfbch2_crcf_analyzer_execute_dev", vp, vp, sz, vp)
 _sig("yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev", vp, vp, sz, ci, ci, vp)
 _sig("yagi_hip_firpfbch2_crcf_assemble_dev", vp, sz, sz, ci, vp, vp)
+
+# ---- multi-GPU (RCCL through the C ABI) ---------------------------------------------------------
+_sig("yagi_hip_comm_unique_id", vp)
+_sig("yagi_hip_comm_create", vp, ci, ci, pvp)
+_sig("yagi_hip_comm_destroy", vp)
+_sig("yagi_hip_comm_rank", vp, C.POINTER(ci), C.POINTER(ci))
+_sig("yagi_hip_comm_all_gather_dev", vp, vp, vp, sz, vp)
+_sig("yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev", vp, vp, sz, vp, ci, vp)

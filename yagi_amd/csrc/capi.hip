@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <memory>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace yagi {
@@ -559,6 +561,7 @@ struct PfbCh2 {
     DevWindow<cf32> syn_hist;  // synthesizer: the last (4m-1)*M channel samples; its own step parity
     uint64_t syn_step = 0;
     Workspace ws;
+    DevBuf shard, gathered;    // sharded analyzer: this rank's sub-bands, and every rank's ([rank][step][M/R] per chunk)
 };
 
 }  // namespace yagi
@@ -823,6 +826,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     }                                                                                               \
     int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s) {                \
         CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
@@ -953,6 +957,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     }                                                                                               \
     int yagi_hip_firdecim_##K##_set_stream(yagi_hip_firdecim_##K q, yagi_stream_t s) {              \
         CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
@@ -1052,6 +1057,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     }                                                                                               \
     int yagi_hip_firpfb_##K##_set_stream(yagi_hip_firpfb_##K q, yagi_stream_t s) {                  \
         CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
@@ -1335,6 +1341,7 @@ struct FirInterp {
     }                                                                                               \
     int yagi_hip_firinterp_##K##_set_stream(yagi_hip_firinterp_##K q, yagi_stream_t s) {            \
         CHECK_Q(q);                                                                                 \
+        if (q->bank.st == to_stream(s)) return YAGI_OK;                                             \
         YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
         q->bank.st = to_stream(s);                                                                  \
         return YAGI_OK;                                                                             \
@@ -1490,6 +1497,7 @@ struct RresampObj {
     }                                                                                               \
     int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s) {                \
         CHECK_Q(q);                                                                                 \
+        if (q->bank.st == to_stream(s)) return YAGI_OK;                                             \
         YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
         q->bank.st = to_stream(s);                                                                  \
         return YAGI_OK;                                                                             \
@@ -1726,6 +1734,7 @@ struct SpgramObj {
     }                                                                                               \
     int yagi_hip_spgram##K##_set_stream(yagi_hip_spgram##K q, yagi_stream_t s) {                    \
         CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
@@ -1955,13 +1964,14 @@ struct FftFiltObj {
         } else {                                                                                    \
             YG_HIP(hipMemcpyAsync(o->w[o->cur].p, q->w[q->cur].p, (size_t)q->n * sizeof(cf32),      \
                                   hipMemcpyDeviceToDevice, q->st));                                 \
-            YG_HIP(hipStreamSynchronize(q->st));                                                    \
+        YG_HIP(hipStreamSynchronize(q->st));                                                    \
         }                                                                                           \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
     }                                                                                               \
     int yagi_hip_fftfilt_##K##_set_stream(yagi_hip_fftfilt_##K q, yagi_stream_t s) {                \
         CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
@@ -2040,6 +2050,7 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
 int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) { delete q; return YAGI_OK; }
 int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s) {
     CHECK_Q(q);
+    if (q->fir.st == to_stream(s)) return YAGI_OK;
     YG_HIP(hipStreamSynchronize(q->fir.st));
     q->fir.st = to_stream(s);
     return YAGI_OK;
@@ -2167,6 +2178,7 @@ int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip
 int yagi_hip_firpfbch_crcf_destroy(yagi_hip_firpfbch_crcf q) { delete q; return YAGI_OK; }
 int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s) {
     CHECK_Q(q);
+    if (q->st == to_stream(s)) return YAGI_OK;      // unchanged: no host synchronisation
     YG_HIP(hipStreamSynchronize(q->st));
     q->st = to_stream(s);
     return YAGI_OK;
@@ -2272,6 +2284,7 @@ int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float 
 int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q) { delete q; return YAGI_OK; }
 int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s) {
     CHECK_Q(q);
+    if (q->st == to_stream(s)) return YAGI_OK;      // unchanged: no host synchronisation
     YG_HIP(hipStreamSynchronize(q->st));
     q->st = to_stream(s);
     return YAGI_OK;
@@ -2332,6 +2345,49 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const ya
     YG_TRY(upload(q->ws.x.p, x, bin, q->st));
     YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nsteps, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, bout, q->st);
+}
+// sub-bands sharded over the ranks of `comm`: shard kernel (this stream) -> RCCL all-gather -> assemble (the
+// communicator's stream), chunk by chunk so chunk k's exchange runs beside chunk k+1's kernel
+int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps,
+                                                         yagi_hip_comm comm, int nchunks, yagi_cf32 *y) {
+    CHECK_Q(q);
+    if (!comm) return fail(YAGI_ERR_CONFIG, "null communicator");
+    if (nsteps == 0) return YAGI_OK;
+    CHECK_PTR(x);
+    CHECK_PTR(y);
+    const int R = comm->nranks, rank = comm->rank;
+    if (R == 1 && nchunks >= 0) return yagi_hip_firpfbch2_crcf_analyzer_execute_dev(q, x, nsteps, y);
+    if (q->M % R) return fail(YAGI_ERR_CONFIG, "firpfbch2: %d channels do not shard over %d ranks", q->M, R);
+    const size_t M = (size_t)q->M, Mr = M / (size_t)R, M2 = M / 2;
+    // chunks: even step counts (the column kernels start on an even step), at least 2048 steps each
+    size_t nc = nchunks ? (size_t)(nchunks < 0 ? -nchunks : nchunks) : 8;
+    while (nc > 1 && nsteps / nc < 2048) --nc;
+    size_t per = (nsteps + nc - 1) / nc;
+    per += per & 1;
+    YG_TRY(q->shard.ensure(nsteps * Mr * sizeof(cf32)));
+    YG_TRY(q->gathered.ensure(nsteps * M * sizeof(cf32)));
+    while (comm->ev.size() < nc) {
+        hipEvent_t e;
+        YG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        comm->ev.push_back(e);
+    }
+    // the exchange stream must not run ahead of work already queued on the object's stream that still reads y
+    size_t done = 0, k = 0;
+    while (done < nsteps) {
+        const size_t ns = std::min(per, nsteps - done);
+        cf32 *sh = q->shard.as<cf32>() + done * Mr;
+        cf32 *ga = q->gathered.as<cf32>() + done * M;
+        YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(q, x + done * M2, ns, rank, R, sh));
+        YG_HIP(hipEventRecord(comm->ev[k], q->st));
+        YG_HIP(hipStreamWaitEvent(comm->st, comm->ev[k], 0));
+        YG_TRY(comm_all_gather(comm, sh, ga, ns * Mr * sizeof(cf32), comm->st));
+        YG_TRY(launch_firpfbch2_assemble(ga, ns, (int)M, R, y + done * M, comm->st));
+        done += ns;
+        ++k;
+    }
+    YG_HIP(hipEventRecord(comm->done, comm->st));
+    YG_HIP(hipStreamWaitEvent(q->st, comm->done, 0));
+    return YAGI_OK;
 }
 int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered, size_t nsteps, size_t M, int nranks,
                                          yagi_cf32 *y, yagi_stream_t s) {

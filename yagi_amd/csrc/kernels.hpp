@@ -11,6 +11,22 @@ struct RRRF { using T = float; using C = float; static constexpr int id = 0; };
 struct CRCF { using T = cf32;  using C = float; static constexpr int id = 1; };
 struct CCCF { using T = cf32;  using C = cf32;  static constexpr int id = 2; };
 
+// ---- comm.cpp --------------------------------------------------------------------------------
+}  // namespace yagi
+// RCCL communicator handle of the C ABI (yagi_hip_comm): the ncclComm_t, this rank, a side stream for the collectives
+// and the events that chain it to an object's stream
+struct yagi_hip_comm_s {
+    void *nccl = nullptr;
+    int rank = 0, nranks = 1;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t done = nullptr;
+};
+namespace yagi {
+using Comm = yagi_hip_comm_s;
+// all-gather `bytes_per_rank` bytes from every rank into recv (rank-major), asynchronous on st
+int comm_all_gather(Comm *c, const void *send, void *recv, size_t bytes_per_rank, hipStream_t st);
+
 // ---- misc_kernels.hip ----------------------------------------------------------------------
 int launch_gen_real(uint64_t seed, uint64_t first, size_t n, float *x, hipStream_t st);
 int launch_gen_complex(uint64_t seed, uint64_t first, size_t n, cf32 *x, hipStream_t st);

@@ -31,6 +31,67 @@ def stream_offset(rank, nranks):
     return int(rank) << 40
 
 
+class Comm:
+    """RCCL communicator owned through the C ABI (yagi_hip_comm_*): what a Rust / C host would hold.
+    `Comm.from_torch_dist()` bootstraps it from an initialised torch.distributed group: rank 0 draws the
+    128-byte unique id, the group broadcasts it, every rank joins (the current HIP device is the rank's GPU)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, uid, rank, nranks):
+        import ctypes as C
+        from . import _check, lib
+        buf = (C.c_ubyte * self.ID_BYTES).from_buffer_copy(bytes(uid))
+        h = C.c_void_p()
+        _check(lib.yagi_hip_comm_create(buf, int(rank), int(nranks), C.byref(h)))
+        self._h = h
+        r, n = C.c_int(), C.c_int()
+        _check(lib.yagi_hip_comm_rank(self._h, C.byref(r), C.byref(n)))
+        self.rank, self.nranks = r.value, n.value        # as RCCL reports them (ncclCommUserRank / ncclCommCount)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _check, lib
+        buf = (C.c_ubyte * Comm.ID_BYTES)()
+        _check(lib.yagi_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_dist(cls, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls(cls.unique_id(), 0, 1)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+        dev = device if (on_gpu and device is not None) else (torch.device("cuda", torch.cuda.current_device())
+                                                              if on_gpu else torch.device("cpu"))
+        t = torch.zeros(cls.ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0, group=group)
+        return cls(bytes(t.cpu().tolist()), rank, world)
+
+    def all_gather_dev(self, send_dev, recv_dev, bytes_per_rank, stream=None):
+        from . import _check, _devptr, lib
+        _check(lib.yagi_hip_comm_all_gather_dev(self._h, _devptr(send_dev), _devptr(recv_dev), bytes_per_rank, stream))
+
+    def destroy(self):
+        h, self._h = getattr(self, "_h", None), None
+        if not h:
+            return
+        try:
+            from . import lib
+        except Exception:          # interpreter shutting down: the process exit releases the communicator
+            return
+        if lib is not None:
+            lib.yagi_hip_comm_destroy(h)
+
+    def __del__(self):
+        self.destroy()
+
+
 def all_gather_subbands(shard, group=None):
     """all-gather equal-size shard tensors into one [world * shard.numel()] tensor (rank-major)"""
     import torch
