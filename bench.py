@@ -180,7 +180,7 @@ def main():
             dist.init_process_group(backend=args.dist_backend)
 
     if args.workload == "c5":
-        from yagi_amd import bench_c5
+        import bench_c5
         out = bench_c5.run(args, rank, world, dev)
         if rank == 0:
             print(json.dumps(out))

@@ -1,4 +1,4 @@
-"""bench.py --workload c5: BASELINE configs[4] -- firpfbch2_crcf 256-channel analyzer, output sub-bands sharded over
+"""bench_c5.py -- bench.py --workload c5: BASELINE configs[4] -- firpfbch2_crcf 256-channel analyzer, output sub-bands sharded over
 the ranks (rank r computes k = r + R q from the full input stream), RCCL all-gather over xGMI, assemble
 (reference semantics: none in the reference, see DESIGN.md "firpfbch2").
 
