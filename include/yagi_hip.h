@@ -299,6 +299,7 @@ YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
                                              float as_, yagi_hip_rresamp_##K *q);                   \
     int yagi_hip_rresamp_##K##_create_default(size_t interp, size_t decim, yagi_hip_rresamp_##K *q);\
     int yagi_hip_rresamp_##K##_destroy(yagi_hip_rresamp_##K q);                                     \
+    int yagi_hip_rresamp_##K##_clone(yagi_hip_rresamp_##K q, yagi_hip_rresamp_##K *out); /* derive(Clone) :8 */ \
     int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s);                 \
     int yagi_hip_rresamp_##K##_reset(yagi_hip_rresamp_##K q);                                       \
     int yagi_hip_rresamp_##K##_set_scale(yagi_hip_rresamp_##K q, C scale);                          \
@@ -316,6 +317,62 @@ YAGI_FIRINTERP_API(cccf, yagi_cf32, yagi_cf32)
 YAGI_RRESAMP_API(rrrf, float, float)
 YAGI_RRESAMP_API(crcf, yagi_cf32, float)
 YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
+
+/* ---- Resamp2<T,Coeff>: src/filter/resampler/resamp2.rs:26-180 (half-band filter / 2-channel bank / x2 resampler)
+ *      MsResamp2<T,Coeff>: src/filter/resampler/msresamp2.rs:8-198 (2^S resampler = chain of half-band stages)
+ *   create(hf, m, f0)        new(m, f0, as_) :44-88 FROM THE DESIGNED PROTOTYPE hf[4m+1]: the reference designs it with
+ *                            fir_design_pm_halfband_stopband_attenuation (Parks-McClellan design code, outside the hot
+ *                            path); everything after the design -- for_halfband modulation :9-23, the 2m branch taps
+ *                            h1[i] = h[4m - 1 - 2i] :66-70, two 2m-sample windows, toggle -- is reproduced.
+ *   create_kaiser(m, f0, as) the reference's signature with a Kaiser-windowed half-band prototype (kaiser(4m+1, 0.25, as))
+ *   clone / reset / set_scale / get_scale / get_delay (= 2m - 1)                     :25,90-106
+ *   execute_block[_dev](mode, x, nx, y): nx input samples through one of the five forms, state carried across calls
+ *       mode 0 filter_execute       :108-130  nx samples  -> 2 nx outputs, (y0, y1) = (low, high) per sample
+ *       mode 1 analyzer_execute     :132-143  nx/2 pairs  -> nx outputs,   (low, high) per pair
+ *       mode 2 synthesizer_execute  :145-157  nx/2 pairs (low, high) -> nx outputs
+ *       mode 3 decim_execute        :159-169  nx samples  -> nx/2 outputs
+ *       mode 4 interp_execute       :171-180  nx samples  -> 2 nx outputs
+ *     (modes 1-3 need an even nx.)  The per-call forms of the reference are these with nx = 1 or 2.
+ *   msresamp2 create(interp, num_stages, fc, f0, as)  new() :38-93 with Kaiser half-band stages (stage plan :66-88:
+ *                            estimate_req_filter_len, m = max(3, ceil((h_len - 1) / 4)), as + 5 dB)
+ *   msresamp2 create_taps(interp, num_stages, m_stage, hf_all)  the same from externally designed stage prototypes
+ *                            (hf_all = the stages' hf[4 m_s + 1] one after the other)
+ *   msresamp2 execute_block[_dev](x, n, y)  n times execute() :137-152: interp n -> n 2^S, decim n 2^S -> n (x 1/2^S)
+ *   msresamp2 get_params     get_type / get_num_stages / get_delay :95-135 (+ the stage semi-lengths) */
+#define YAGI_RESAMP2_API(K, T, C)                                                                   \
+    typedef struct yagi_hip_resamp2_##K##_s *yagi_hip_resamp2_##K;                                  \
+    typedef struct yagi_hip_msresamp2_##K##_s *yagi_hip_msresamp2_##K;                              \
+    int yagi_hip_resamp2_##K##_create(const float *hf, size_t m, float f0, yagi_hip_resamp2_##K *q);\
+    int yagi_hip_resamp2_##K##_create_kaiser(size_t m, float f0, float as_, yagi_hip_resamp2_##K *q);\
+    int yagi_hip_resamp2_##K##_destroy(yagi_hip_resamp2_##K q);                                     \
+    int yagi_hip_resamp2_##K##_clone(yagi_hip_resamp2_##K q, yagi_hip_resamp2_##K *out);            \
+    int yagi_hip_resamp2_##K##_reset(yagi_hip_resamp2_##K q);                                       \
+    int yagi_hip_resamp2_##K##_set_stream(yagi_hip_resamp2_##K q, yagi_stream_t s);                 \
+    int yagi_hip_resamp2_##K##_set_scale(yagi_hip_resamp2_##K q, C scale);                          \
+    int yagi_hip_resamp2_##K##_get_scale(yagi_hip_resamp2_##K q, C *scale);                         \
+    int yagi_hip_resamp2_##K##_get_delay(yagi_hip_resamp2_##K q, size_t *delay);                    \
+    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x,          \
+                                             size_t nx, T *y);                                      \
+    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x_dev,  \
+                                                 size_t nx, T *y_dev);                              \
+    int yagi_hip_msresamp2_##K##_create(int interp, size_t num_stages, float fc, float f0,          \
+                                        float as_, yagi_hip_msresamp2_##K *q);                      \
+    int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
+                                             const float *hf_all, yagi_hip_msresamp2_##K *q);       \
+    int yagi_hip_msresamp2_##K##_destroy(yagi_hip_msresamp2_##K q);                                 \
+    int yagi_hip_msresamp2_##K##_clone(yagi_hip_msresamp2_##K q, yagi_hip_msresamp2_##K *out);      \
+    int yagi_hip_msresamp2_##K##_reset(yagi_hip_msresamp2_##K q);                                   \
+    int yagi_hip_msresamp2_##K##_set_stream(yagi_hip_msresamp2_##K q, yagi_stream_t s);             \
+    int yagi_hip_msresamp2_##K##_get_params(yagi_hip_msresamp2_##K q, int *interp,                  \
+                                            size_t *num_stages, float *delay, size_t *m_stage);     \
+    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n,      \
+                                               T *y);                                               \
+    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x_dev,        \
+                                                   size_t n, T *y_dev);
+
+YAGI_RESAMP2_API(rrrf, float, float)
+YAGI_RESAMP2_API(crcf, yagi_cf32, float)
+YAGI_RESAMP2_API(cccf, yagi_cf32, yagi_cf32)
 
 /* Which kernel execute_block uses.  0 = auto (always a direct form), 1 = general direct-form kernels
  * (fir_kernels.hip: register-window kernel for blocks >= 512 samples, interleaved-output kernel below; both add

@@ -131,6 +131,25 @@ def lib():
         L.yo_fftfilt_reset.argtypes = [vp]
         L.yo_fftfilt_set_scale.argtypes = [vp, fp, fp]
         L.yo_fftfilt_execute.argtypes = [vp, vp, vp]
+        for k, (T, Cc, _) in (("rrrf", (fp, fp, 0)), ("crcf", (cf32, fp, 1)), ("cccf", (cf32, cf32, 2))):
+            r = "yo_resamp2_" + k
+            getattr(L, r + "_create").restype = vp
+            getattr(L, r + "_create").argtypes = [vp, sz, fp]
+            getattr(L, r + "_destroy").argtypes = [vp]
+            getattr(L, r + "_clone").restype = vp
+            getattr(L, r + "_clone").argtypes = [vp]
+            getattr(L, r + "_reset").argtypes = [vp]
+            getattr(L, r + "_set_scale").argtypes = [vp, Cc]
+            getattr(L, r + "_execute_block").argtypes = [vp, C.c_int, vp, sz, vp]
+            m_ = "yo_msresamp2_" + k
+            getattr(L, m_ + "_create").restype = vp
+            getattr(L, m_ + "_create").argtypes = [C.c_int, sz, vp, vp, Cc]
+            getattr(L, m_ + "_destroy").argtypes = [vp]
+            getattr(L, m_ + "_execute_block").argtypes = [vp, vp, sz, vp]
+        L.yo_estimate_req_filter_len.restype = sz
+        L.yo_estimate_req_filter_len.argtypes = [fp, fp]
+        L.yo_msresamp2_stage_lengths.restype = C.c_int
+        L.yo_msresamp2_stage_lengths.argtypes = [sz, fp, fp, vp]
         _lib = L
     return _lib
 
@@ -765,6 +784,111 @@ class Spgram:
         if q.num_transforms == 0:
             q.step()
         return q.get_psd()
+
+
+def halfband_kaiser(m, as_):
+    """a half-band prototype hf[4m+1] for Resamp2 (the reference designs its own with Parks-McClellan,
+    fir_design_pm_halfband_stopband_attenuation -- design code, out of scope): Kaiser-windowed sinc at fc = 0.25.
+    fir_design_kaiser returns sinc(2 fc t) w(t) (centre tap 1, DC gain 1 / (2 fc) = 2); a half-band prototype has
+    centre tap 1/2 and unit DC gain, hence the factor 0.5 (exact in f32).  Only the odd-offset taps are ever used
+    (resamp2.rs:66-70); the centre is implied by the delay branch (:113,140)."""
+    return (np.float32(0.5) * fir_design_kaiser(4 * m + 1, 0.25, as_)).astype(np.float32)
+
+
+class Resamp2:
+    """resamp2.rs:26-174 over a given half-band prototype hf[4m+1]"""
+    MODES = {"filter": 0, "analyzer": 1, "synthesizer": 2, "decim": 3, "interp": 4}
+
+    def __init__(self, kind, hf, m, f0=0.0, _h=None):
+        self.kind, self.m = kind, int(m)
+        self.T = KINDS[kind][0]
+        if _h is not None:
+            self.h = _h
+            return
+        hf = _as(hf, np.float32)
+        if len(hf) != 4 * m + 1:
+            raise ValueError("config")
+        self.h = getattr(lib(), f"yo_resamp2_{kind}_create")(_p(hf), m, f0)
+        if not self.h:
+            raise ValueError("config")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                getattr(lib(), f"yo_resamp2_{self.kind}_destroy")(self.h)
+        except Exception:              # interpreter shutting down
+            pass
+
+    def clone(self):
+        return Resamp2(self.kind, None, self.m, _h=getattr(lib(), f"yo_resamp2_{self.kind}_clone")(self.h))
+
+    def reset(self):
+        getattr(lib(), f"yo_resamp2_{self.kind}_reset")(self.h)
+
+    def set_scale(self, s):
+        getattr(lib(), f"yo_resamp2_{self.kind}_set_scale")(self.h, _scalar(self.kind, s, coeff=True))
+
+    def get_delay(self):
+        return 2 * self.m - 1
+
+    def execute_block(self, mode, x):
+        """mode: filter (n -> 2n, (y0,y1) pairs), analyzer / synthesizer (n pairs -> n pairs), decim (2n -> n),
+        interp (n -> 2n)"""
+        x = _as(x, self.T)
+        md = self.MODES[mode]
+        n = len(x) if md in (0, 4) else len(x) // 2
+        y = np.empty(n if md == 3 else 2 * n, self.T)
+        getattr(lib(), f"yo_resamp2_{self.kind}_execute_block")(self.h, md, _p(x), n, _p(y))
+        return y
+
+
+def msresamp2_stage_lengths(num_stages, fc, as_):
+    """msresamp2.rs:70-88: semi-length of every half-band stage"""
+    m = np.zeros(max(num_stages, 1), np.uint64)
+    if lib().yo_msresamp2_stage_lengths(num_stages, fc, as_, _p(m)):
+        raise ValueError("config")
+    return [int(v) for v in m[:num_stages]]
+
+
+class MsResamp2:
+    """msresamp2.rs:8-198 with Kaiser half-band stages (stage attenuation as_ + 5, :69)"""
+
+    def __init__(self, kind, interp, num_stages, fc, f0, as_):
+        if f0 != 0.0:
+            raise ValueError("config")
+        self.kind, self.interp, self.num_stages, self.rate = kind, bool(interp), num_stages, 1 << num_stages
+        self.T = KINDS[kind][0]
+        self.m_stage = msresamp2_stage_lengths(num_stages, fc, as_)
+        hf = np.concatenate([halfband_kaiser(m, as_ + 5.0) for m in self.m_stage]) if num_stages else np.zeros(1, np.float32)
+        ms = np.array(self.m_stage or [0], np.uint64)
+        zeta = _scalar(kind, 1.0 / self.rate, coeff=True)
+        self.h = getattr(lib(), f"yo_msresamp2_{kind}_create")(int(self.interp), num_stages, _p(ms), _p(_as(hf, np.float32)), zeta)
+        if not self.h:
+            raise ValueError("config")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                getattr(lib(), f"yo_msresamp2_{self.kind}_destroy")(self.h)
+        except Exception:
+            pass
+
+    def get_delay(self):                                          # :118-135
+        d = 0.0
+        if self.interp:
+            for i in range(self.num_stages):
+                d = d * 0.5 + self.m_stage[self.num_stages - i - 1]
+        else:
+            for i in range(self.num_stages):
+                d = d * 2.0 + 2.0 * self.m_stage[i] - 1.0
+        return d
+
+    def execute_block(self, x):
+        x = _as(x, self.T)
+        n = len(x) if self.interp else len(x) // self.rate
+        y = np.empty(n * self.rate if self.interp else n, self.T)
+        getattr(lib(), f"yo_msresamp2_{self.kind}_execute_block")(self.h, _p(x), n, _p(y))
+        return y
 
 
 def stream_fir_fft(h, scale, x, nfft):

@@ -745,3 +745,192 @@ void yo_stream_fir_fft(yo_firfilt_crcf *q, const yo_fft_plan *p, const cf32 *x, 
         yo_fft_run_f32(p, scratch, spectra + f * n);
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * Resamp2<T,Coeff>  --  src/filter/resampler/resamp2.rs:26-174
+ * MsResamp2<T,Coeff> -- src/filter/resampler/msresamp2.rs:8-198
+ *
+ * new() (resamp2.rs:44-88) designs its half-band prototype with fir_design_pm_halfband_stopband_attenuation
+ * (Parks-McClellan design code: out of the hot path's scope).  The restatement therefore takes the designed
+ * prototype hf[4m+1] as an argument and follows the reference from there: modulation (for_halfband :12-22), the
+ * 2m taps h1[i] = h[h_len - 2i - 2] (:66-70), two Window<T> of 2m samples, toggle.
+ * Arithmetic is spelled as the reference spells it: 0.5 * (yi + yq) * scale etc.
+ * ---------------------------------------------------------------------------------- */
+static const float YO_PI_F = 3.14159265358979323846f;   /* std::f32::consts::PI */
+static inline float r_sub(float a, float b) { return a - b; }
+static inline cf32 c_sub(cf32 a, cf32 b) { cf32 r = { a.re - b.re, a.im - b.im }; return r; }
+static inline float r_half(float a) { return 0.5f * a; }
+static inline cf32 c_half(cf32 a) { cf32 r = { 0.5f * a.re, 0.5f * a.im }; return r; }   /* T::from(0.5) * a, im(0.5) = 0: */
+/* Complex(0.5,0) * a = (0.5 a.re - 0 a.im, 0.5 a.im + 0 a.re): equal bit for bit to the component form for finite a */
+static inline float halfband_r(float hf, float t, float f0) { return 2.0f * hf * cosf(2.0f * YO_PI_F * t * f0); }
+static inline cf32 halfband_c(float hf, float t, float f0) {
+    float g = 2.0f * hf, a = 2.0f * YO_PI_F * t * f0;
+    cf32 r = { g * cosf(a), g * sinf(a) };
+    return r;
+}
+static inline float dot_rr(const float *h, const float *r, size_t n) { return yo_dotprod_rrrf(h, r, n); }
+static inline cf32 dot_rc(const float *h, const cf32 *r, size_t n) { cf32 y; yo_dotprod_rcc(h, r, n, &y); return y; }
+static inline cf32 dot_cc(const cf32 *h, const cf32 *r, size_t n) { cf32 y; yo_dotprod_ccc(h, r, n, &y); return y; }
+
+#define DEFINE_RESAMP2(SUF, T, C, MUL_TC, ADD_T, SUB_T, HALF_T, ONE_C, DOT, HALFBAND)              \
+typedef struct { size_t m; C *h1; yo_window *w0, *w1; C scale; int toggle; } yo_resamp2_##SUF;    \
+yo_resamp2_##SUF *yo_resamp2_##SUF##_create(const float *hf, size_t m, float f0) { /* :44-88 */   \
+    if (m < 2) return NULL;                                                                       \
+    if (f0 < -0.5f || f0 > 0.5f) return NULL;                                                     \
+    size_t h_len = 4 * m + 1;                                                                     \
+    C *h = (C *)malloc(h_len * sizeof(C));                                                        \
+    for (size_t i = 0; i < h_len; i++) {                                                          \
+        float t = (float)i - (float)(h_len - 1) / 2.0f;                                           \
+        h[i] = HALFBAND(hf[i], t, f0);                                                            \
+    }                                                                                             \
+    yo_resamp2_##SUF *q = (yo_resamp2_##SUF *)calloc(1, sizeof(*q));                              \
+    q->m = m; q->h1 = (C *)malloc(2 * m * sizeof(C));                                             \
+    for (size_t i = 0; i < 2 * m; i++) q->h1[i] = h[h_len - 2 * i - 2];                           \
+    free(h);                                                                                      \
+    q->w0 = yo_window_create(2 * m, sizeof(T)); q->w1 = yo_window_create(2 * m, sizeof(T));       \
+    q->scale = ONE_C; q->toggle = 0;                                                              \
+    return q;                                                                                     \
+}                                                                                                 \
+void yo_resamp2_##SUF##_destroy(yo_resamp2_##SUF *q) {                                            \
+    if (q) { free(q->h1); yo_window_destroy(q->w0); yo_window_destroy(q->w1); free(q); }          \
+}                                                                                                 \
+yo_resamp2_##SUF *yo_resamp2_##SUF##_clone(const yo_resamp2_##SUF *s) {      /* derive(Clone) :25 */ \
+    yo_resamp2_##SUF *q = (yo_resamp2_##SUF *)calloc(1, sizeof(*q));                              \
+    q->m = s->m; q->h1 = (C *)malloc(2 * s->m * sizeof(C)); memcpy(q->h1, s->h1, 2 * s->m * sizeof(C)); \
+    q->w0 = yo_window_clone(s->w0); q->w1 = yo_window_clone(s->w1); q->scale = s->scale; q->toggle = s->toggle; \
+    return q;                                                                                     \
+}                                                                                                 \
+void yo_resamp2_##SUF##_reset(yo_resamp2_##SUF *q) {                          /* :90-94 */        \
+    yo_window_reset(q->w0); yo_window_reset(q->w1); q->toggle = 0;                                \
+}                                                                                                 \
+void yo_resamp2_##SUF##_set_scale(yo_resamp2_##SUF *q, C s) { q->scale = s; } /* :96-98 */        \
+void yo_resamp2_##SUF##_filter_execute(yo_resamp2_##SUF *q, T x, T *y0, T *y1) { /* :108-130 */   \
+    T yi, yq;                                                                                     \
+    if (!q->toggle) {                                                                             \
+        yo_window_push(q->w0, &x); yo_window_index(q->w0, q->m - 1, &yi);                         \
+        yq = DOT(q->h1, (const T *)yo_window_read(q->w1), 2 * q->m);                              \
+    } else {                                                                                      \
+        yo_window_push(q->w1, &x); yo_window_index(q->w1, q->m - 1, &yi);                         \
+        yq = DOT(q->h1, (const T *)yo_window_read(q->w0), 2 * q->m);                              \
+    }                                                                                             \
+    q->toggle = !q->toggle;                                                                       \
+    *y0 = MUL_TC(HALF_T(ADD_T(yi, yq)), q->scale);                                                \
+    *y1 = MUL_TC(HALF_T(SUB_T(yi, yq)), q->scale);                                                \
+}                                                                                                 \
+void yo_resamp2_##SUF##_analyzer_execute(yo_resamp2_##SUF *q, const T *x, T *y) { /* :132-143 */  \
+    T a = HALF_T(x[0]), b = HALF_T(x[1]), y0;                                                     \
+    yo_window_push(q->w1, &a);                                                                    \
+    T y1 = DOT(q->h1, (const T *)yo_window_read(q->w1), 2 * q->m);                                \
+    yo_window_push(q->w0, &b); yo_window_index(q->w0, q->m - 1, &y0);                             \
+    y[0] = MUL_TC(ADD_T(y1, y0), q->scale);                                                       \
+    y[1] = MUL_TC(SUB_T(y1, y0), q->scale);                                                       \
+}                                                                                                 \
+void yo_resamp2_##SUF##_synthesizer_execute(yo_resamp2_##SUF *q, const T *x, T *y) { /* :145-157 */ \
+    T x0 = ADD_T(x[0], x[1]), x1 = SUB_T(x[0], x[1]), d;                                          \
+    yo_window_push(q->w0, &x0); yo_window_index(q->w0, q->m - 1, &d);                             \
+    y[0] = MUL_TC(d, q->scale);                                                                   \
+    yo_window_push(q->w1, &x1);                                                                   \
+    y[1] = MUL_TC(DOT(q->h1, (const T *)yo_window_read(q->w1), 2 * q->m), q->scale);              \
+}                                                                                                 \
+T yo_resamp2_##SUF##_decim_execute(yo_resamp2_##SUF *q, const T *x) {        /* :159-169 */       \
+    T y0;                                                                                         \
+    yo_window_push(q->w1, &x[0]);                                                                 \
+    T y1 = DOT(q->h1, (const T *)yo_window_read(q->w1), 2 * q->m);                                \
+    yo_window_push(q->w0, &x[1]); yo_window_index(q->w0, q->m - 1, &y0);                          \
+    return MUL_TC(ADD_T(y0, y1), q->scale);                                                       \
+}                                                                                                 \
+void yo_resamp2_##SUF##_interp_execute(yo_resamp2_##SUF *q, T x, T *y) {     /* :171-180 */       \
+    T d;                                                                                          \
+    yo_window_push(q->w0, &x); yo_window_index(q->w0, q->m - 1, &d);                              \
+    y[0] = MUL_TC(d, q->scale);                                                                   \
+    yo_window_push(q->w1, &x);                                                                    \
+    y[1] = MUL_TC(DOT(q->h1, (const T *)yo_window_read(q->w1), 2 * q->m), q->scale);              \
+}                                                                                                 \
+/* block forms: the per-call functions above, n times (mode 0 filter: n in -> 2n out as (y0,y1) pairs;           \
+ * 1 analyzer / 2 synthesizer: n pairs -> n pairs; 3 decim: 2n -> n; 4 interp: n -> 2n) */                       \
+void yo_resamp2_##SUF##_execute_block(yo_resamp2_##SUF *q, int mode, const T *x, size_t n, T *y) {               \
+    for (size_t i = 0; i < n; i++) {                                                              \
+        switch (mode) {                                                                           \
+        case 0: yo_resamp2_##SUF##_filter_execute(q, x[i], &y[2 * i], &y[2 * i + 1]); break;      \
+        case 1: yo_resamp2_##SUF##_analyzer_execute(q, x + 2 * i, y + 2 * i); break;              \
+        case 2: yo_resamp2_##SUF##_synthesizer_execute(q, x + 2 * i, y + 2 * i); break;           \
+        case 3: y[i] = yo_resamp2_##SUF##_decim_execute(q, x + 2 * i); break;                     \
+        default: yo_resamp2_##SUF##_interp_execute(q, x[i], y + 2 * i); break;                    \
+        }                                                                                         \
+    }                                                                                             \
+}                                                                                                 \
+                                                                                                  \
+/* ---- MsResamp2: msresamp2.rs:8-198; stage prototypes hf_s[4 m_s + 1] supplied (design out of scope) ---- */  \
+typedef struct { int interp; size_t num_stages, rate; C zeta; T *b0, *b1; yo_resamp2_##SUF **st; } yo_msresamp2_##SUF; \
+yo_msresamp2_##SUF *yo_msresamp2_##SUF##_create(int interp, size_t num_stages, const size_t *m_stage,            \
+                                                 const float *hf_all, C zeta) {   /* :38-93 */    \
+    if (num_stages > 16) return NULL;                                                             \
+    yo_msresamp2_##SUF *q = (yo_msresamp2_##SUF *)calloc(1, sizeof(*q));                          \
+    q->interp = interp; q->num_stages = num_stages; q->rate = (size_t)1 << num_stages; q->zeta = zeta; \
+    q->b0 = (T *)calloc(q->rate, sizeof(T)); q->b1 = (T *)calloc(q->rate, sizeof(T));             \
+    q->st = (yo_resamp2_##SUF **)calloc(num_stages ? num_stages : 1, sizeof(*q->st));             \
+    for (size_t i = 0; i < num_stages; i++) {                                                     \
+        q->st[i] = yo_resamp2_##SUF##_create(hf_all, m_stage[i], 0.0f);      /* f0_stage = 0 (:44-46) */ \
+        hf_all += 4 * m_stage[i] + 1;                                                             \
+    }                                                                                             \
+    return q;                                                                                     \
+}                                                                                                 \
+void yo_msresamp2_##SUF##_destroy(yo_msresamp2_##SUF *q) {                                        \
+    if (!q) return;                                                                               \
+    for (size_t i = 0; i < q->num_stages; i++) yo_resamp2_##SUF##_destroy(q->st[i]);              \
+    free(q->st); free(q->b0); free(q->b1); free(q);                                               \
+}                                                                                                 \
+void yo_msresamp2_##SUF##_interp_execute(yo_msresamp2_##SUF *q, T x, T *y) {  /* :154-175 */      \
+    T *b0 = q->b0, *b1 = q->b1;                                                                   \
+    b0[0] = x;                                                                                    \
+    for (size_t s = 0; s < q->num_stages; s++) {                                                  \
+        size_t k = (size_t)1 << s;                                                                \
+        for (size_t i = 0; i < k; i++) yo_resamp2_##SUF##_interp_execute(q->st[s], b0[i], &b1[2 * i]); \
+        T *t = b0; b0 = b1; b1 = t;                                                               \
+    }                                                                                             \
+    memcpy(y, b0, q->rate * sizeof(T));                                                           \
+}                                                                                                 \
+T yo_msresamp2_##SUF##_decim_execute(yo_msresamp2_##SUF *q, const T *x) {     /* :177-197 */      \
+    T *b0 = q->b0, *b1 = q->b1;                                                                   \
+    memcpy(b0, x, q->rate * sizeof(T));                                                           \
+    for (size_t s = 0; s < q->num_stages; s++) {                                                  \
+        size_t k = (size_t)1 << (q->num_stages - s - 1), g = q->num_stages - s - 1;               \
+        for (size_t i = 0; i < k; i++) b1[i] = yo_resamp2_##SUF##_decim_execute(q->st[g], &b0[2 * i]); \
+        T *t = b0; b0 = b1; b1 = t;                                                               \
+    }                                                                                             \
+    return MUL_TC(b0[0], q->zeta);                                                                \
+}                                                                                                 \
+/* n execute() calls (:137-152): interp n -> n*rate, decim n*rate -> n; num_stages = 0 copies */  \
+void yo_msresamp2_##SUF##_execute_block(yo_msresamp2_##SUF *q, const T *x, size_t n, T *y) {      \
+    for (size_t i = 0; i < n; i++) {                                                              \
+        if (q->num_stages == 0) y[i] = x[i];                                                      \
+        else if (q->interp) yo_msresamp2_##SUF##_interp_execute(q, x[i], y + i * q->rate);        \
+        else y[i] = yo_msresamp2_##SUF##_decim_execute(q, x + i * q->rate);                       \
+    }                                                                                             \
+}
+
+DEFINE_RESAMP2(rrrf, float, float, r_mul, r_add, r_sub, r_half, 1.0f, dot_rr, halfband_r)
+DEFINE_RESAMP2(crcf, cf32, float, c_mulr, c_add, c_sub, c_half, 1.0f, dot_rc, halfband_r)
+DEFINE_RESAMP2(cccf, cf32, cf32, c_mul, c_add, c_sub, c_half, CONE, dot_cc, halfband_c)
+
+/* estimate_req_filter_len (design/mod.rs:138-152, Kaiser's formula :228-238) and the per-stage semi-lengths of
+ * MsResamp2::new (msresamp2.rs:70-88); returns 0 on a configuration error */
+size_t yo_estimate_req_filter_len(float df, float as_) {
+    if (df <= 0.0f || df > 0.5f || as_ <= 0.0f) return 0;
+    float h_len = (as_ - 7.95f) / (14.26f * df);
+    return (size_t)h_len;                    /* `n as usize`: saturating truncation toward zero */
+}
+int yo_msresamp2_stage_lengths(size_t num_stages, float fc, float as_, size_t *m_stage) {
+    if (num_stages > 16 || fc <= 0.0f || fc >= 0.5f) return YO_ECONFIG;
+    float a = as_ + 5.0f;
+    for (size_t i = 0; i < num_stages; i++) {
+        fc = (i == 1) ? (0.5f - fc) / 2.0f : 0.5f * fc;
+        float ft = 2.0f * (0.25f - fc);
+        if (ft <= 0.0f || ft > 0.5f || a <= 0.0f) return YO_ECONFIG;
+        float hl = (a - 7.95f) / (14.26f * ft);
+        size_t h_len = hl <= 0.0f ? 0 : (size_t)hl;
+        size_t m = (size_t)ceilf(((float)h_len - 1.0f) / 4.0f);
+        m_stage[i] = m < 3 ? 3 : m;
+    }
+    return YO_OK;
+}

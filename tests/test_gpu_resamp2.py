@@ -1,0 +1,222 @@
+"""Resamp2 / MsResamp2 through the C ABI (HIP kernels) -- SURVEY.md section 8(f-4).
+
+Mirrors src/filter/resampler/resamp2.rs:183-399 and msresamp2.rs:199-337: the reference's tests for these objects
+are property tests (tone analysis / synthesis, spectral masks of impulse responses, config, copy) -- the same
+harness as tests/test_oracle_resamp2.py, run here on the GPU objects -- plus sample-level parity with the oracle's
+restatement on the same prototypes: bit-exact on integer-valued data (indexing: which sample meets which tap, the
+delay branch, the toggle), rel. L2 <= 2e-6 on Gaussian data.  Prototype VALUES are Kaiser half-band (the reference's
+Parks-McClellan design is out of scope): "parity unpinned" for the taps, pinned for everything after them."""
+import numpy as np
+import pytest
+
+from gpu_util import SEED, int_samples, rand_samples, rel_l2
+from test_oracle_resamp2 import filter_masks, msresamp2_interp_mask, two_band_synthesis, two_tone_analysis
+
+pytestmark = pytest.mark.gpu
+KINDS = ["rrrf", "crcf", "cccf"]
+MODES = ["filter", "analyzer", "synthesizer", "decim", "interp"]
+
+
+@pytest.fixture(scope="module")
+def ya():
+    import yagi_amd
+    assert yagi_amd.device_count() > 0
+    return yagi_amd
+
+
+class _G:
+    """GPU object with the oracle wrapper's execute_block(mode_name, x)"""
+    def __init__(self, ya, kind, m, as_=60.0, f0=0.0, hf=None):
+        self.ya = ya
+        self.q = ya.Resamp2.new(kind, m, f0, as_) if hf is None else ya.Resamp2(kind, hf, m, f0)
+
+    def execute_block(self, mode, x):
+        return self.q.execute_block(MODES.index(mode), x)
+
+
+def int_halfband(rng, m):
+    """integer-valued 'prototype': exact arithmetic, so any indexing slip changes the output"""
+    return rng.integers(-3, 4, 4 * m + 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("mode", MODES)
+def test_forms_bit_exact_on_integers(ya, oracle, kind, mode):
+    rng = np.random.default_rng(7)
+    for m in (2, 5, 17):
+        hf = int_halfband(rng, m)
+        g = ya.Resamp2(kind, hf, m, 0.0)
+        o = oracle.Resamp2(kind, hf, m, 0.0)
+        g.set_scale(2.0)
+        o.set_scale(2.0)
+        # three calls: state carried; odd lengths for the sample-wise forms (the toggle flips between calls)
+        sizes = (301, 1, 778) if mode in ("filter", "interp") else (300, 2, 778)
+        for n in sizes:
+            x = int_samples(rng, kind, n) * (2 if mode == "analyzer" else 1)      # analyzer halves its input
+            got = g.execute_block(MODES.index(mode), x)
+            want = o.execute_block(mode, x)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want), (kind, mode, m, n)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_forms_vs_oracle_gaussian(ya, oracle, kind):
+    rng = np.random.default_rng(8)
+    for m, f0 in ((4, 0.0), (12, 0.11 if kind == "cccf" else 0.0), (30, 0.0)):
+        hf = oracle.halfband_kaiser(m, 70.0)
+        for mode in MODES:
+            g = ya.Resamp2(kind, hf, m, f0)
+            o = oracle.Resamp2(kind, hf, m, f0)
+            x = rand_samples(rng, kind, 4096 + 2 * 333)
+            got = np.concatenate([g.execute_block(MODES.index(mode), x[:666]), g.execute_block(MODES.index(mode), x[666:])])
+            want = np.concatenate([o.execute_block(mode, x[:666]), o.execute_block(mode, x[666:])])
+            assert rel_l2(got, want) <= 2e-6, (kind, mode, m)
+
+
+def test_f0_modulation_rrrf_crcf(ya, oracle):
+    """for_halfband (resamp2.rs:9-23): real coefficients take the cosine only"""
+    m = 6
+    hf = oracle.halfband_kaiser(m, 60.0)
+    x = rand_samples(np.random.default_rng(3), "crcf", 512)
+    for kind in ("crcf", "cccf"):
+        got = ya.Resamp2(kind, hf, m, 0.2).execute_block(3, x)
+        want = oracle.Resamp2(kind, hf, m, 0.2).execute_block("decim", x)
+        assert rel_l2(got, want) <= 2e-6
+
+
+def test_reference_tone_tests_on_gpu(ya):
+    assert two_tone_analysis(lambda m: _G(ya, "crcf", m)) <= 1e-3               # resamp2.rs:189-229
+    assert two_band_synthesis(lambda m: _G(ya, "crcf", m)) <= 3e-3              # :231-268
+
+
+@pytest.mark.parametrize("m,as_", [(4, 60.0), (7, 60.0), (12, 60.0), (15, 80.0), (15, 100.0), (15, 120.0)])
+def test_reference_filter_masks_on_gpu(ya, m, as_):                             # :270-336
+    (ok0, w0), (ok1, w1) = filter_masks(lambda mm, a: _G(ya, "crcf", mm, a), m, as_, 0.5)
+    assert ok0 and ok1, (w0, w1)
+
+
+def test_config_copy_reset(ya, oracle):                                         # :338-399
+    for bad in [lambda: ya.Resamp2.new("crcf", 0, 0.0, 60.0), lambda: ya.Resamp2.new("crcf", 1, 0.0, 60.0),
+                lambda: ya.Resamp2.new("crcf", 2, 0.7, 60.0), lambda: ya.Resamp2.new("crcf", 2, -0.7, 60.0),
+                lambda: ya.Resamp2.new("crcf", 2, 0.0, -1.0), lambda: ya.Resamp2("crcf", np.zeros(16, np.float32), 4)]:
+        with pytest.raises(ya.ConfigError):
+            bad()
+    assert ya.Resamp2.new("crcf", 4, 0.0, 60.0).get_delay() == 7
+    q = ya.Resamp2.new("crcf", 8, 0.0, 80.0)
+    assert q.get_delay() == 15
+    q.set_scale(7.22)
+    assert q.get_scale() == np.float32(7.22)
+    with pytest.raises(ya.ConfigError):
+        q.execute_block(3, np.zeros(5, np.complex64))                           # decim consumes pairs
+    with pytest.raises(ya.ConfigError):
+        q.execute_block(9, np.zeros(4, np.complex64))
+    # copy: a clone taken mid-stream (odd count: toggle set) continues identically; reset restarts
+    qa = ya.Resamp2.new("crcf", 12, 0.0, 60.0)
+    x = oracle.gen_complex(SEED + 9, 241)
+    first = qa.execute_block(0, x[:81])
+    qb = qa.clone()
+    assert np.array_equal(qa.execute_block(0, x[81:]), qb.execute_block(0, x[81:]))
+    qa.reset()
+    assert np.array_equal(qa.execute_block(0, x[:81]), first)
+    # the per-call forms
+    qc, qd = ya.Resamp2.new("crcf", 5, 0.0, 60.0), ya.Resamp2.new("crcf", 5, 0.0, 60.0)
+    blk = qd.execute_block(0, x[:6]).reshape(-1, 2)
+    for i in range(6):
+        y0, y1 = qc.filter_execute(x[i])
+        assert (y0, y1) == (blk[i, 0], blk[i, 1])
+
+
+def test_large_block_device_path(ya, oracle):
+    """2^22 samples through the device entry point: interp then decim of the same half-band pair returns the input
+    delayed by 2m - 1 + ... (unit pass-band gain), and the decimator's every output matches the oracle on a window"""
+    m, n = 10, 1 << 22
+    x = ya.gen_complex_dev(SEED + 9, n)
+    up = ya.DeviceArray(2 * n, np.complex64)
+    dn = ya.DeviceArray(n, np.complex64)
+    qi, qd = ya.Resamp2.new("crcf", m, 0.0, 60.0), ya.Resamp2.new("crcf", m, 0.0, 60.0)
+    qi.execute_block_dev(ya.Resamp2.INTERP, x, n, up)
+    qd.execute_block_dev(ya.Resamp2.DECIM, up, 2 * n, dn)
+    ya.synchronize()
+    xs = x.to_numpy()
+    hf = oracle.halfband_kaiser(m, 60.0)
+    oi, od = oracle.Resamp2("crcf", hf, m), oracle.Resamp2("crcf", hf, m)
+    k = 1 << 14
+    want = od.execute_block("decim", oi.execute_block("interp", xs[:k]))
+    assert rel_l2(dn.to_numpy(k), want) <= 2e-6
+    # deep inside the block: recompute a window with the history it needs
+    lo = n - 4096
+    oi2, od2 = oracle.Resamp2("crcf", hf, m), oracle.Resamp2("crcf", hf, m)
+    w = od2.execute_block("decim", oi2.execute_block("interp", xs[lo - 8 * m:]))
+    assert rel_l2(dn.to_numpy(4096, lo), w[8 * m:]) <= 2e-6
+
+
+# ---- MsResamp2 ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,fc,as_", [(1, 0.25, 60.0), (2, 0.25, 60.0), (3, 0.25, 60.0), (4, 0.25, 60.0),
+                                       (1, 0.45, 60.0), (2, 0.45, 60.0), (3, 0.45, 60.0), (4, 0.45, 60.0),
+                                       (3, 0.45, 80.0), (3, 0.45, 90.0), (3, 0.45, 100.0)])
+def test_msresamp2_reference_interp_masks_on_gpu(ya, ns, fc, as_):              # msresamp2.rs:206-298
+    ok, worst = msresamp2_interp_mask(lambda s, f, a: ya.MsResamp2("crcf", ya.MsResamp2.INTERP, s, f, 0.0, a), ns, fc, as_)
+    assert ok, worst
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("interp", [True, False])
+def test_msresamp2_vs_oracle(ya, oracle, kind, interp):
+    rng = np.random.default_rng(12)
+    for ns, fc in ((0, 0.3), (1, 0.25), (3, 0.45), (5, 0.4)):
+        g = ya.MsResamp2(kind, ya.MsResamp2.INTERP if interp else ya.MsResamp2.DECIM, ns, fc, 0.0, 60.0)
+        o = oracle.MsResamp2(kind, interp, ns, fc, 0.0, 60.0)
+        assert g.get_stage_lengths() == o.m_stage and g.get_num_stages() == ns
+        assert abs(g.get_delay() - o.get_delay()) < 1e-6 and g.get_rate() == (float(1 << ns) if interp else 1.0 / (1 << ns))
+        rate = 1 << ns
+        n1, n2 = 37, 200
+        x = rand_samples(rng, kind, (n1 + n2) * (1 if interp else rate))
+        cut = n1 * (1 if interp else rate)
+        got = np.concatenate([g.execute_block(x[:cut]), g.execute_block(x[cut:])])          # state carried
+        want = np.concatenate([o.execute_block(x[:cut]), o.execute_block(x[cut:])])
+        assert got.shape == want.shape and rel_l2(got, want) <= 3e-6, (kind, interp, ns)
+
+
+def test_msresamp2_config_copy(ya, oracle):                                     # :38-48, :300-337
+    for bad in [lambda: ya.MsResamp2("crcf", 1, 17, 0.4, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.5, 0.0, 60.0),
+                lambda: ya.MsResamp2("crcf", 1, 2, 0.0, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.4, 0.1, 60.0)]:
+        with pytest.raises(ya.ConfigError):
+            bad()
+    q0 = ya.MsResamp2("crcf", ya.MsResamp2.INTERP, 4, 0.4, 0.0, 60.0)
+    x = oracle.gen_complex(SEED + 10, 70)
+    q0.execute_block(x[:35])
+    q1 = q0.clone()
+    assert np.array_equal(q0.execute_block(x[35:]), q1.execute_block(x[35:]))
+    q0.reset()
+    fresh = ya.MsResamp2("crcf", ya.MsResamp2.INTERP, 4, 0.4, 0.0, 60.0)
+    assert np.array_equal(q0.execute_block(x[:35]), fresh.execute_block(x[:35]))
+    # externally designed stage prototypes (what a host with the reference's PM design would pass)
+    ms = [4, 8]
+    hfs = [oracle.halfband_kaiser(m, 65.0) for m in ms]
+    a = ya.MsResamp2.from_taps("crcf", ya.MsResamp2.DECIM, ms, hfs)
+    b = ya.MsResamp2("crcf", ya.MsResamp2.DECIM, 2, 0.25, 0.0, 60.0)
+    assert b.get_stage_lengths() == ms
+    xx = oracle.gen_complex(SEED + 11, 4 * 100)
+    assert rel_l2(a.execute_block(xx), b.execute_block(xx)) <= 1e-6
+
+
+def test_rresamp_clone(ya, oracle):
+    """Rresamp is #[derive(Clone)] (rresamp.rs:8): a clone taken mid-stream continues identically"""
+    q = ya.Rresamp.new_kaiser("crcf", 3, 5, 7, 0.4, 60.0)
+    x = oracle.gen_complex(SEED + 12, 5 * 40)
+    q.execute_block(x[: 5 * 15], 15)
+    c = q.clone()
+    assert np.array_equal(q.execute_block(x[5 * 15:], 25), c.execute_block(x[5 * 15:], 25))
+    assert (c.get_interp(), c.get_decim(), c.get_delay()) == (3, 5, 7)
+
+
+def test_output_array_checks(ya):
+    """caller-supplied output arrays must be contiguous arrays of the object's type and size"""
+    p = ya.Fft(16, ya.Direction.Forward)
+    x = np.ones(16, np.complex64)
+    with pytest.raises(ya.ConfigError):
+        p.run(x, output=np.zeros(16, np.complex128))
+    with pytest.raises(ya.ConfigError):
+        p.run(x, output=np.zeros(32, np.complex64)[::2])
+    out = np.zeros(16, np.complex64)
+    assert p.run(x, output=out) is out and out[0] == 16

@@ -93,6 +93,16 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if isinstance(a, np.ndarray) else C.c_void_p(a)
 
 
+def _out(y, n, dt):
+    """a caller-supplied output array handed to the C ABI as a raw pointer: it must be exactly what the library
+    will write -- dtype dt, C-contiguous, n elements -- or a fresh array when None"""
+    if y is None:
+        return np.empty(n, dt)
+    if not (isinstance(y, np.ndarray) and y.dtype == np.dtype(dt) and y.flags.c_contiguous and y.size == n):
+        raise ConfigError(f"output must be a C-contiguous {np.dtype(dt).name} array of {n} elements")
+    return y
+
+
 def _byval(v, ctype):
     if ctype is cf32:
         v = complex(v)
@@ -586,8 +596,129 @@ class Rresamp(_FirBase):
     def execute_block_dev(self, x_dev, n, y_dev):
         _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
 
-    def clone(self):
-        raise NotImplementedError("Rresamp.clone is not part of the C ABI yet")
+
+
+class Resamp2(_FirBase):
+    """Resamp2<T,Coeff> (src/filter/resampler/resamp2.rs): half-band filter / two-channel bank / x2 resampler.
+    The reference designs its prototype with Parks-McClellan (design code, out of scope): `Resamp2(kind, hf, m, f0)`
+    takes the designed prototype hf[4m+1]; `Resamp2.new(kind, m, f0, as_)` is the reference's constructor signature
+    with a Kaiser-windowed half-band prototype."""
+    FILTER, ANALYZER, SYNTHESIZER, DECIM, INTERP = range(5)
+
+    def __init__(self, kind, hf, m, f0=0.0):                  # new() :44-88, from the designed prototype
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_resamp2_{kind}_"
+        hf = _arr(hf, np.float32)
+        if hf.size != 4 * m + 1:
+            raise ConfigError("half-band prototype must hold 4*m+1 taps")
+        hd = C.c_void_p()
+        _check(self._fn("create")(_ptr(hf), m, f0, C.byref(hd)))
+        self._h, self.m = hd, int(m)
+
+    @classmethod
+    def new(cls, kind, m, f0, as_):                           # Resamp2::new(m, f0, as_) :44
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_resamp2_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn("create_kaiser")(m, f0, as_, C.byref(hd)))
+        self._h, self.m = hd, int(m)
+        return self
+
+    def get_delay(self):                                      # :104-106
+        d = C.c_size_t()
+        _check(self._fn("get_delay")(self._h, C.byref(d)))
+        return d.value
+
+    @staticmethod
+    def _out_count(mode, nx):
+        return 2 * nx if mode in (0, 4) else nx // 2 if mode == 3 else nx
+
+    def execute_block(self, mode, x):
+        x = _arr(x, self.T)
+        y = np.empty(self._out_count(mode, x.size), self.T)
+        _check(self._fn("execute_block")(self._h, mode, _ptr(x), x.size, _ptr(y)))
+        return y
+
+    def execute_block_dev(self, mode, x_dev, nx, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, mode, _devptr(x_dev), nx, _devptr(y_dev)))
+
+    # the reference's per-call forms
+    def filter_execute(self, x):                              # :108-130 -> (y0, y1)
+        y = self.execute_block(self.FILTER, np.array([x], self.T))
+        return y[0], y[1]
+
+    def analyzer_execute(self, x):                            # :132-143  x[2] -> y[2]
+        return self.execute_block(self.ANALYZER, x)
+
+    def synthesizer_execute(self, x):                         # :145-157  x[2] -> y[2]
+        return self.execute_block(self.SYNTHESIZER, x)
+
+    def decim_execute(self, x):                               # :159-169  x[2] -> y
+        return self.execute_block(self.DECIM, x)[0]
+
+    def interp_execute(self, x):                              # :171-180  x -> y[2]
+        return self.execute_block(self.INTERP, np.array([x], self.T))
+
+
+class MsResamp2(_FirBase):
+    """MsResamp2<T,Coeff> (src/filter/resampler/msresamp2.rs): 2^num_stages interpolator / decimator, a chain of
+    half-band stages (Kaiser prototypes; `from_taps` takes externally designed ones)."""
+    DECIM, INTERP = 0, 1                                      # ResampType :27-31
+
+    def __init__(self, kind, type_, num_stages, fc, f0, as_):  # new() :38-93
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_msresamp2_{kind}_"
+        hd = C.c_void_p()
+        _check(self._fn("create")(int(type_), num_stages, fc, f0, as_, C.byref(hd)))
+        self._h = hd
+
+    @classmethod
+    def from_taps(cls, kind, type_, m_stage, hf_stages):
+        self = object.__new__(cls)
+        self._init_kind(kind)
+        self._prefix = f"yagi_hip_msresamp2_{kind}_"
+        ms = np.array(list(m_stage) or [0], np.uint64)
+        hf = _arr(np.concatenate([np.asarray(h, np.float32) for h in hf_stages]) if len(m_stage) else np.zeros(1), np.float32)
+        hd = C.c_void_p()
+        _check(self._fn("create_taps")(int(type_), len(m_stage), _ptr(ms), _ptr(hf), C.byref(hd)))
+        self._h = hd
+        return self
+
+    def _params(self):
+        it, ns, d = C.c_int(), C.c_size_t(), C.c_float()
+        ms = np.zeros(16, np.uint64)
+        _check(self._fn("get_params")(self._h, C.byref(it), C.byref(ns), C.byref(d), _ptr(ms)))
+        return it.value, ns.value, d.value, [int(v) for v in ms[: ns.value]]
+
+    def get_type(self): return self._params()[0]              # :113-115
+    def get_num_stages(self): return self._params()[1]        # :109-111
+    def get_delay(self): return self._params()[2]             # :117-135
+    def get_stage_lengths(self): return self._params()[3]
+    def get_rate(self):                                       # :102-107
+        it, ns, _, _ = self._params()
+        return float(1 << ns) if it else 1.0 / (1 << ns)
+
+    def set_scale(self, scale):
+        raise ConfigError("MsResamp2 has no scale (msresamp2.rs)")
+
+    get_scale = set_scale
+
+    def execute_block(self, x, n=None):
+        """n execute() calls (:137-152): interp: n inputs -> n*rate outputs; decim: n*rate inputs -> n outputs"""
+        x = _arr(x, self.T)
+        it, ns, _, _ = self._params()
+        rate = 1 << ns
+        n = (x.size if it else x.size // rate) if n is None else n
+        y = np.empty(n * rate if it else n, self.T)
+        _check(self._fn("execute_block")(self._h, _ptr(x), n, _ptr(y)))
+        return y
+
+    def execute_block_dev(self, x_dev, n, y_dev):
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+
+    def execute(self, x):                                     # :137-152
+        return self.execute_block(x, 1)
 
 
 class FftFilt(_FirBase):
@@ -611,8 +742,7 @@ class FftFilt(_FirBase):
 
     def execute(self, x, y=None):                            # :103-138
         x = _arr(x, self.T)
-        if y is None:
-            y = np.empty(self.n, self.T)
+        y = _out(y, self.n, self.T)
         _check(self._fn("execute")(self._h, _ptr(x), x.size, _ptr(y), y.size))
         return y
 
@@ -642,7 +772,7 @@ class Fft(_Handle):
 
     def run(self, input, output=None):                       # fft/mod.rs:45-48
         x = _arr(input, np.complex64)
-        y = np.empty(self.n, np.complex64) if output is None else output
+        y = _out(output, self.n, np.complex64)
         _check(lib.yagi_hip_fft_run(self._h, _ptr(x), x.size, _ptr(y), y.size))
         return y
 

@@ -243,3 +243,29 @@ _sig("yagi_hip_comm_destroy", vp)
 _sig("yagi_hip_comm_rank", vp, C.POINTER(ci), C.POINTER(ci))
 _sig("yagi_hip_comm_all_gather_dev", vp, vp, vp, sz, vp)
 _sig("yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev", vp, vp, sz, vp, ci, vp)
+
+# ---- Resamp2 / MsResamp2 and Rresamp clone ---------------------------------
+for _k, (_T, _Cc) in KIND_TYPES.items():
+    _sig(f"yagi_hip_rresamp_{_k}_clone", vp, pvp)
+    p = f"yagi_hip_resamp2_{_k}_"
+    _sig(p + "create", vp, sz, f32, pvp)
+    _sig(p + "create_kaiser", sz, f32, f32, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "clone", vp, pvp)
+    _sig(p + "reset", vp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "set_scale", vp, _Cc)
+    _sig(p + "get_scale", vp, vp)
+    _sig(p + "get_delay", vp, C.POINTER(sz))
+    _sig(p + "execute_block", vp, ci, vp, sz, vp)
+    _sig(p + "execute_block_dev", vp, ci, vp, sz, vp)
+    p = f"yagi_hip_msresamp2_{_k}_"
+    _sig(p + "create", ci, sz, f32, f32, f32, pvp)
+    _sig(p + "create_taps", ci, sz, vp, vp, pvp)
+    _sig(p + "destroy", vp)
+    _sig(p + "clone", vp, pvp)
+    _sig(p + "reset", vp)
+    _sig(p + "set_stream", vp, vp)
+    _sig(p + "get_params", vp, C.POINTER(ci), C.POINTER(sz), C.POINTER(f32), vp)
+    _sig(p + "execute_block", vp, vp, sz, vp)
+    _sig(p + "execute_block_dev", vp, vp, sz, vp)

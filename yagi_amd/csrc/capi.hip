@@ -1495,6 +1495,24 @@ struct RresampObj {
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
     }                                                                                               \
+    int yagi_hip_rresamp_##K##_clone(yagi_hip_rresamp_##K q, yagi_hip_rresamp_##K *out) {  /* derive(Clone) rresamp.rs:8 */ \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        YG_TRY(q->bank.w.flush(q->bank.st));                                                        \
+        auto o = std::make_unique<yagi_hip_rresamp_##K##_s>();                                      \
+        o->bank.st = q->bank.st;                                                                    \
+        o->bank.nf = q->bank.nf;                                                                    \
+        o->bank.Ls = q->bank.Ls;                                                                    \
+        o->bank.hb = q->bank.hb;                                                                    \
+        o->bank.scale = q->bank.scale;                                                              \
+        YG_TRY(o->bank.taps.alloc(o->bank.hb.size() * sizeof(C)));                                  \
+        YG_TRY(upload(o->bank.taps.p, o->bank.hb.data(), o->bank.hb.size() * sizeof(C), o->bank.st)); \
+        YG_TRY(o->bank.w.clone_from(q->bank.w, q->bank.st));                                        \
+        o->P = q->P; o->Q = q->Q; o->m = q->m; o->block_len = q->block_len;                         \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
     int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s) {                \
         CHECK_Q(q);                                                                                 \
         if (q->bank.st == to_stream(s)) return YAGI_OK;                                             \
@@ -2398,3 +2416,364 @@ int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered, size_t nstep
 }
 
 }  // extern "C"
+
+
+// ---- Resamp2 / MsResamp2 (src/filter/resampler/resamp2.rs, msresamp2.rs) ---------------
+namespace yagi {
+
+// Resamp2Coeff::for_halfband (resamp2.rs:9-23), f32 arithmetic as the reference spells it
+static float for_halfband(float hf, float t, float f0, float *) {
+    const float pi = 3.14159265358979323846f;
+    return 2.0f * hf * std::cos(2.0f * pi * t * f0);
+}
+static cf32 for_halfband(float hf, float t, float f0, cf32 *) {
+    const float pi = 3.14159265358979323846f;
+    const float g = 2.0f * hf, a = 2.0f * pi * t * f0;
+    return cf32{g * std::cos(a), g * std::sin(a)};
+}
+
+template <class K>
+struct Resamp2Obj {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    int m = 0;
+    std::vector<C> h1;             // h1[i] = h[h_len - 2i - 2] (resamp2.rs:66-70)
+    DevBuf h1d;
+    DevBuf state[2];               // [w0 (2m, oldest first)][w1 (2m)], ping-pong
+    int cur = 0;
+    int toggle = 0;
+    C scale;
+    Workspace ws;
+
+    // new() from the designed half-band prototype hf[4m+1] (:44-88)
+    int init(const float *hf, size_t m_, float f0) {
+        if (m_ < 2) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 2");
+        if (m_ > (size_t)kR2MaxSemiLen) return fail(YAGI_ERR_CONFIG, "filter semi-length must not exceed %d", kR2MaxSemiLen);
+        if (f0 < -0.5f || f0 > 0.5f) return fail(YAGI_ERR_CONFIG, "f0 (%g) must be in [-0.5,0.5]", (double)f0);
+        m = (int)m_;
+        const size_t h_len = 4 * m_ + 1;
+        std::vector<C> h(h_len);
+        for (size_t i = 0; i < h_len; ++i) {
+            const float t = (float)i - (float)(h_len - 1) / 2.0f;
+            h[i] = for_halfband(hf[i], t, f0, (C *)nullptr);
+        }
+        h1.resize(2 * m_);
+        for (size_t i = 0; i < 2 * m_; ++i) h1[i] = h[h_len - 2 * i - 2];
+        scale = to_c(1.0f, (C *)nullptr);
+        YG_TRY(h1d.alloc(h1.size() * sizeof(C)));
+        YG_TRY(upload(h1d.p, h1.data(), h1.size() * sizeof(C), st));
+        YG_TRY(state[0].alloc(4 * m_ * sizeof(T)));
+        YG_TRY(state[1].alloc(4 * m_ * sizeof(T)));
+        return reset();
+    }
+    int reset() {                                                   // :90-94
+        toggle = 0;
+        YG_HIP(hipMemsetAsync(state[cur].p, 0, 4 * (size_t)m * sizeof(T), st));
+        return YAGI_OK;
+    }
+    static size_t out_count(int mode, size_t nx) {
+        return mode == kR2Filter || mode == kR2Interp ? 2 * nx : mode == kR2Decim ? nx / 2 : nx;
+    }
+    int block_dev(int mode, const T *x, size_t nx, T *y) {
+        if (mode < kR2Filter || mode > kR2Interp) return fail(YAGI_ERR_CONFIG, "resamp2: unknown form %d", mode);
+        if (mode != kR2Filter && mode != kR2Interp && (nx & 1))
+            return fail(YAGI_ERR_CONFIG, "resamp2: this form consumes pairs of samples (got %zu)", nx);
+        if (nx == 0) return YAGI_OK;
+        YG_TRY((launch_resamp2<T, C>(mode, state[cur].template as<T>(), x, nx, h1d.template as<C>(), m, scale, toggle, y,
+                                     state[1 - cur].template as<T>(), st)));
+        cur = 1 - cur;
+        if (mode == kR2Filter) toggle = (toggle + (int)(nx & 1)) & 1;
+        return YAGI_OK;
+    }
+    int block_host(int mode, const T *x, size_t nx, T *y) {
+        if (nx == 0) return YAGI_OK;
+        const size_t ny = out_count(mode, nx);
+        YG_TRY(ws.x.ensure(nx * sizeof(T)));
+        YG_TRY(ws.y.ensure((ny ? ny : 1) * sizeof(T)));
+        YG_TRY(upload(ws.x.p, x, nx * sizeof(T), st));
+        YG_TRY(block_dev(mode, ws.x.template as<T>(), nx, ws.y.template as<T>()));
+        return download(y, ws.y.p, ny * sizeof(T), st);
+    }
+    int clone_into(Resamp2Obj &o) const {
+        o.st = st;
+        o.m = m;
+        o.h1 = h1;
+        o.toggle = toggle;
+        o.scale = scale;
+        o.cur = 0;
+        YG_TRY(o.h1d.alloc(h1.size() * sizeof(C)));
+        YG_TRY(upload(o.h1d.p, h1.data(), h1.size() * sizeof(C), st));
+        YG_TRY(o.state[0].alloc(4 * (size_t)m * sizeof(T)));
+        YG_TRY(o.state[1].alloc(4 * (size_t)m * sizeof(T)));
+        YG_HIP(hipMemcpyAsync(o.state[0].p, state[cur].p, 4 * (size_t)m * sizeof(T), hipMemcpyDeviceToDevice, st));
+        YG_HIP(hipStreamSynchronize(st));
+        return YAGI_OK;
+    }
+};
+
+// estimate_req_filter_len (design/mod.rs:138-152 with Kaiser's formula :228-238) and MsResamp2::new's stage plan
+// (msresamp2.rs:66-88): semi-length of every half-band stage
+static int msresamp2_stage_lengths(size_t num_stages, float fc, float as_, std::vector<size_t> &m_stage) {
+    if (num_stages > 16) return fail(YAGI_ERR_CONFIG, "number of stages should not exceed 16");
+    if (fc <= 0.0f || fc >= 0.5f) return fail(YAGI_ERR_CONFIG, "cut-off frequency must be in (0,0.5)");
+    m_stage.assign(num_stages, 0);
+    const float a = as_ + 5.0f;
+    for (size_t i = 0; i < num_stages; ++i) {
+        fc = (i == 1) ? (0.5f - fc) / 2.0f : 0.5f * fc;
+        const float ft = 2.0f * (0.25f - fc);
+        if (ft <= 0.0f || ft > 0.5f) return fail(YAGI_ERR_CONFIG, "cutoff frequency (%g) out of range (0, 0.5)", (double)ft);
+        if (a <= 0.0f) return fail(YAGI_ERR_CONFIG, "stopband attenuation must be greater than zero");
+        const float hl = (a - 7.95f) / (14.26f * ft);
+        const size_t h_len = hl <= 0.0f ? 0 : (size_t)hl;
+        const size_t mm = (size_t)std::ceil(((float)h_len - 1.0f) / 4.0f);
+        m_stage[i] = mm < 3 ? 3 : mm;
+    }
+    return YAGI_OK;
+}
+
+template <class K>
+struct MsResamp2Obj {
+    using T = typename K::T;
+    using C = typename K::C;
+    hipStream_t st = nullptr;
+    bool interp = false;
+    size_t num_stages = 0, rate = 1;
+    std::vector<size_t> m_stage;
+    std::vector<std::unique_ptr<Resamp2Obj<K>>> stage;
+    DevBuf buf[2];
+    Workspace ws;
+
+    int init(bool interp_, size_t ns, const size_t *ms, const float *hf_all) {
+        if (ns > 16) return fail(YAGI_ERR_CONFIG, "number of stages should not exceed 16");
+        interp = interp_;
+        num_stages = ns;
+        rate = (size_t)1 << ns;
+        m_stage.assign(ms, ms + ns);
+        for (size_t i = 0; i < ns; ++i) {
+            auto s = std::make_unique<Resamp2Obj<K>>();
+            s->st = st;
+            YG_TRY(s->init(hf_all, ms[i], 0.0f));                    // f0_stage = 0 (msresamp2.rs:44-46)
+            hf_all += 4 * ms[i] + 1;
+            stage.push_back(std::move(s));
+        }
+        // the decimator's zeta = 1/rate multiplies the last stage's output (:197); folded into that stage's scale
+        // (its scale is 1, so (y0 + y1) * 1 * zeta == (y0 + y1) * zeta bit for bit)
+        if (!interp && ns) stage[0]->scale = to_c(1.0f / (float)rate, (C *)nullptr);
+        return YAGI_OK;
+    }
+    // n execute() calls: interp n -> n*rate, decim n*rate -> n (device pointers)
+    int block_dev(const T *x, size_t n, T *y) {
+        if (n == 0) return YAGI_OK;
+        if (num_stages == 0) {
+            YG_HIP(hipMemcpyAsync(y, x, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+            return YAGI_OK;
+        }
+        const size_t big = n * rate;
+        if (num_stages > 1) {                                        // ping-pong intermediates: at most big/2 samples
+            YG_TRY(buf[0].ensure(big / 2 * sizeof(T)));
+            YG_TRY(buf[1].ensure(big / 2 * sizeof(T)));
+        }
+        const T *src = x;
+        int pp = 0;
+        if (interp) {                                                // stage s doubles n 2^s samples (:154-175)
+            size_t cnt = n;
+            for (size_t s = 0; s < num_stages; ++s) {
+                const bool last = s + 1 == num_stages;
+                T *dst = last ? y : buf[pp].template as<T>();
+                YG_TRY(stage[s]->block_dev(kR2Interp, src, cnt, dst));
+                src = dst;
+                cnt *= 2;
+                pp ^= 1;
+            }
+        } else {                                                     // stages g = S-1 .. 0, each halves (:177-197)
+            size_t cnt = big;
+            for (size_t s = 0; s < num_stages; ++s) {
+                const size_t g = num_stages - 1 - s;
+                const bool last = g == 0;
+                T *dst = last ? y : buf[pp].template as<T>();
+                YG_TRY(stage[g]->block_dev(kR2Decim, src, cnt, dst));
+                src = dst;
+                cnt /= 2;
+                pp ^= 1;
+            }
+        }
+        return YAGI_OK;
+    }
+    int block_host(const T *x, size_t n, T *y) {
+        if (n == 0) return YAGI_OK;
+        const size_t nin = interp ? n : n * rate, nout = interp ? n * rate : n;
+        YG_TRY(ws.x.ensure(nin * sizeof(T)));
+        YG_TRY(ws.y.ensure(nout * sizeof(T)));
+        YG_TRY(upload(ws.x.p, x, nin * sizeof(T), st));
+        YG_TRY(block_dev(ws.x.template as<T>(), n, ws.y.template as<T>()));
+        return download(y, ws.y.p, nout * sizeof(T), st);
+    }
+    float delay() const {                                            // :118-135
+        float d = 0.0f;
+        if (interp) {
+            for (size_t i = 0; i < num_stages; ++i) { d *= 0.5f; d += (float)m_stage[num_stages - i - 1]; }
+        } else {
+            for (size_t i = 0; i < num_stages; ++i) { d *= 2.0f; d += 2.0f * (float)m_stage[i] - 1.0f; }
+        }
+        return d;
+    }
+};
+
+}  // namespace yagi
+
+#define YAGI_RESAMP2_IMPL(K, KT, T, C)                                                              \
+    struct yagi_hip_resamp2_##K##_s : Resamp2Obj<KT> {};                                            \
+    struct yagi_hip_msresamp2_##K##_s : MsResamp2Obj<KT> {};                                        \
+    extern "C" {                                                                                    \
+    int yagi_hip_resamp2_##K##_create(const float *hf, size_t m, float f0, yagi_hip_resamp2_##K *q) { \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        CHECK_PTR(hf);                                                                              \
+        auto o = std::make_unique<yagi_hip_resamp2_##K##_s>();                                      \
+        YG_TRY(o->init(hf, m, f0));                                                                 \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_create_kaiser(size_t m, float f0, float as_, yagi_hip_resamp2_##K *q) { \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (m < 2) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 2");           \
+        if (f0 < -0.5f || f0 > 0.5f) return fail(YAGI_ERR_CONFIG, "f0 (%g) must be in [-0.5,0.5]", (double)f0); \
+        if (as_ < 0.0f) return fail(YAGI_ERR_CONFIG, "as (%g) must be greater than zero", (double)as_); \
+        if (m > (size_t)kR2MaxSemiLen) return fail(YAGI_ERR_CONFIG, "filter semi-length must not exceed %d", kR2MaxSemiLen); \
+        std::vector<float> hf;                                                                      \
+        YG_TRY(design_kaiser(4 * m + 1, 0.25f, as_ > 0.0f ? as_ : 1e-3f, 0.0f, hf));                \
+        for (float &v : hf) v *= 0.5f;                 /* sinc(t/2) w(t) has centre 1: half-band = centre 1/2 */ \
+        return yagi_hip_resamp2_##K##_create(hf.data(), m, f0, q);                                  \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_destroy(yagi_hip_resamp2_##K q) { delete q; return YAGI_OK; }        \
+    int yagi_hip_resamp2_##K##_clone(yagi_hip_resamp2_##K q, yagi_hip_resamp2_##K *out) {           \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        auto o = std::make_unique<yagi_hip_resamp2_##K##_s>();                                      \
+        YG_TRY(q->clone_into(*o));                                                                  \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_reset(yagi_hip_resamp2_##K q) { CHECK_Q(q); return q->reset(); }     \
+    int yagi_hip_resamp2_##K##_set_stream(yagi_hip_resamp2_##K q, yagi_stream_t s) {                \
+        CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_set_scale(yagi_hip_resamp2_##K q, C scale) { CHECK_Q(q); q->scale = scale; return YAGI_OK; } \
+    int yagi_hip_resamp2_##K##_get_scale(yagi_hip_resamp2_##K q, C *scale) {                        \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(scale);                                                                           \
+        *scale = q->scale;                                                                          \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_get_delay(yagi_hip_resamp2_##K q, size_t *delay) {                   \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(delay);                                                                           \
+        *delay = 2 * (size_t)q->m - 1;                                                              \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) { \
+        CHECK_Q(q);                                                                                 \
+        if (nx == 0) return YAGI_OK;                                                                \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_host(mode, x, nx, y);                                                       \
+    }                                                                                               \
+    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) { \
+        CHECK_Q(q);                                                                                 \
+        if (nx == 0) return YAGI_OK;                                                                \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(mode, x, nx, y);                                                        \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
+                                             const float *hf_all, yagi_hip_msresamp2_##K *q) {      \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        if (num_stages) { CHECK_PTR(m_stage); CHECK_PTR(hf_all); }                                  \
+        auto o = std::make_unique<yagi_hip_msresamp2_##K##_s>();                                    \
+        YG_TRY(o->init(interp != 0, num_stages, m_stage, hf_all));                                  \
+        *q = o.release();                                                                           \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_create(int interp, size_t num_stages, float fc, float f0, float as_, \
+                                        yagi_hip_msresamp2_##K *q) {                                \
+        CHECK_PTR(q);                                                                               \
+        *q = nullptr;                                                                               \
+        std::vector<size_t> ms;                                                                     \
+        YG_TRY(msresamp2_stage_lengths(num_stages, fc, as_, ms));                                   \
+        if (f0 != 0.0f) return fail(YAGI_ERR_CONFIG, "non-zero center frequency not yet supported"); \
+        std::vector<float> all, hf;                                                                 \
+        for (size_t i = 0; i < num_stages; ++i) {                                                   \
+            YG_TRY(design_kaiser(4 * ms[i] + 1, 0.25f, as_ + 5.0f, 0.0f, hf));                      \
+            for (float &v : hf) v *= 0.5f;                                                          \
+            all.insert(all.end(), hf.begin(), hf.end());                                            \
+        }                                                                                           \
+        return yagi_hip_msresamp2_##K##_create_taps(interp, num_stages, ms.data(), all.data(), q);  \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_destroy(yagi_hip_msresamp2_##K q) { delete q; return YAGI_OK; }    \
+    int yagi_hip_msresamp2_##K##_clone(yagi_hip_msresamp2_##K q, yagi_hip_msresamp2_##K *out) {     \
+        CHECK_Q(q);                                                                                 \
+        CHECK_PTR(out);                                                                             \
+        *out = nullptr;                                                                             \
+        auto o = std::make_unique<yagi_hip_msresamp2_##K##_s>();                                    \
+        o->st = q->st;                                                                              \
+        o->interp = q->interp;                                                                      \
+        o->num_stages = q->num_stages;                                                              \
+        o->rate = q->rate;                                                                          \
+        o->m_stage = q->m_stage;                                                                    \
+        for (auto &s : q->stage) {                                                                  \
+            auto c = std::make_unique<Resamp2Obj<KT>>();                                            \
+            YG_TRY(s->clone_into(*c));                                                              \
+            o->stage.push_back(std::move(c));                                                       \
+        }                                                                                           \
+        *out = o.release();                                                                         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_reset(yagi_hip_msresamp2_##K q) {                                  \
+        CHECK_Q(q);                                                                                 \
+        for (auto &s : q->stage) YG_TRY(s->reset());                                                \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_set_stream(yagi_hip_msresamp2_##K q, yagi_stream_t s) {            \
+        CHECK_Q(q);                                                                                 \
+        if (q->st == to_stream(s)) return YAGI_OK;                                                  \
+        YG_HIP(hipStreamSynchronize(q->st));                                                        \
+        q->st = to_stream(s);                                                                       \
+        for (auto &g : q->stage) g->st = q->st;                                                     \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_get_params(yagi_hip_msresamp2_##K q, int *interp, size_t *num_stages, \
+                                            float *delay, size_t *m_stage) {                        \
+        CHECK_Q(q);                                                                                 \
+        if (interp) *interp = q->interp ? 1 : 0;                                                    \
+        if (num_stages) *num_stages = q->num_stages;                                                \
+        if (delay) *delay = q->delay();                                                             \
+        if (m_stage) for (size_t i = 0; i < q->num_stages; ++i) m_stage[i] = q->m_stage[i];         \
+        return YAGI_OK;                                                                             \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) { \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_host(x, n, y);                                                              \
+    }                                                                                               \
+    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) { \
+        CHECK_Q(q);                                                                                 \
+        if (n == 0) return YAGI_OK;                                                                 \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        return q->block_dev(x, n, y);                                                               \
+    }                                                                                               \
+    }
+
+YAGI_RESAMP2_IMPL(rrrf, RRRF, float, float)
+YAGI_RESAMP2_IMPL(crcf, CRCF, yagi_cf32, float)
+YAGI_RESAMP2_IMPL(cccf, CCCF, yagi_cf32, yagi_cf32)

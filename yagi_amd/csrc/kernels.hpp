@@ -111,6 +111,16 @@ int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs_
 
 int launch_scale_cf32(const cf32 *src, float s, cf32 *dst, size_t n, hipStream_t st);
 
+// ---- resamp2_kernels.hip -------------------------------------------------------------------
+// forms of Resamp2 (resamp2.rs:104-180); values are the `mode` argument of the C ABI
+enum { kR2Filter = 0, kR2Analyzer = 1, kR2Synthesizer = 2, kR2Decim = 3, kR2Interp = 4 };
+constexpr int kR2MaxSemiLen = 1024;
+// one block of nx input samples; state = [w0 (2m, oldest first)][w1 (2m)]; state_next receives the windows after the
+// block (must not alias state).  Outputs: filter 2 nx ((y0,y1) pairs), analyzer / synthesizer nx, decim nx/2, interp 2 nx.
+template <class T, class C>
+int launch_resamp2(int mode, const T *state, const T *x, size_t nx, const C *h1, int m, C scale, int toggle, T *y,
+                   T *state_next, hipStream_t st);
+
 // ---- fft_kernels.hip -----------------------------------------------------------------------
 struct FftPlanDev {
     int n = 0;

@@ -93,12 +93,19 @@ class Comm:
 
 
 def all_gather_subbands(shard, group=None):
-    """all-gather equal-size shard tensors into one [world * shard.numel()] tensor (rank-major)"""
+    """all-gather equal-size shard tensors into one [world * shard.numel()] tensor (rank-major).  Backend nccl (=
+    RCCL) gathers device tensors in place; gloo (CPU tests, or several ranks sharing one GPU) goes through the host."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty(world * shard.numel(), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(out, shard.reshape(-1).contiguous(), group=group)
+    flat = shard.reshape(-1).contiguous()
+    if flat.is_cuda and dist.get_backend(group) != "nccl":
+        host = flat.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return torch.cat(parts).to(shard.device)
+    out = torch.empty(world * flat.numel(), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
     return out
 
 
