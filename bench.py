@@ -355,6 +355,16 @@ def main():
         leg("C5_firpfbch2_256ch_1gpu", lambda: c5.analyzer_execute_dev(xp, nc // 128, yp), nc, 24,
             f"firpfbch2_crcf analyzer M=256 m=4 As=60, {nc} input samples -> {2 * nc} outputs, all sub-bands on "
             "one GPU (the sharded form: bench.py --workload c5)")
+        r2 = ya.Resamp2.new("crcf", 12, 0.0, 60.0)
+        r2.set_stream(stream.cuda_stream)
+        leg("F4_resamp2_crcf_decim", lambda: r2.execute_block_dev(ya.Resamp2.DECIM, xp, nc, yp), nc, 12,
+            f"Resamp2<Complex32,f32> m=12 (24-tap half-band branch + delay), decim_execute over {nc} samples "
+            "(SURVEY 8f-4): 8 B in + 4 B out per input sample, 2 launches")
+        ms2 = ya.MsResamp2("crcf", ya.MsResamp2.DECIM, 3, 0.4, 0.0, 60.0)
+        ms2.set_stream(stream.cuda_stream)
+        leg("F4_msresamp2_crcf_decim8", lambda: ms2.execute_block_dev(xp, nc // 8, yp), nc, 9,
+            f"MsResamp2 decimator by 8 (3 half-band stages, {ms2.get_stage_lengths()}), {nc} input samples; "
+            "algorithmic bytes 8 in + 1 out per input sample (stage intermediates stay in HBM: 8+4+4+2+2+1 actual)")
         extras["configs"] = cfg
 
     kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",

@@ -20,6 +20,10 @@
  *     (thread-local), like the String each Error variant carries.
  *   - Pointers are HOST pointers unless the function name ends in `_dev`, in which case data
  *     pointers are device (HBM) pointers and the call is asynchronous on the handle's stream.
+ *   - NO ALIASING: the input and output ranges of a `_dev` block call must not overlap (no in-place
+ *     execution): the kernels read tile halos and the carried window from the input while other
+ *     workgroups already store the output.  Rust's borrows (`&[T]` in, `&mut [T]` out) make such a
+ *     call unwritable in the reference; here it returns YAGI_ERR_CONFIG.
  *   - A handle owns its device taps, its device window (the filter state), a workspace and a
  *     stream reference.  One handle = one owner thread at a time (the reference's `&mut self`);
  *     distinct handles may be used concurrently.  Fft plans are read-only once created.

@@ -142,13 +142,29 @@ def main():
         print(f"{name}.npz: {len(d)} arrays, {sum(a.size for a in d.values())} values")
 
 
+def fft4096_definition_vectors(check_only=False):
+    """fft4096.npz is NOT transcribed from the reference (it holds no vector above N = 509, and its FFT arithmetic
+    lives in the rustfft crate, not in the tree): 4 transforms of the C3 stream, input from the oracle's generator
+    (seed 0x59414749 + 3), output by DEFINITION (unnormalised forward DFT) from numpy's f64 FFT.  Needs only the repo,
+    so it also runs where /root/reference is absent; with check_only it verifies the committed file instead."""
+    import sys
+    sys.path.insert(0, str(HERE.parent.parent))
+    from oracle import oracle
+    x = oracle.gen_complex(0x59414749 + 3, 4 * 4096)
+    y = np.array([np.fft.fft(x[b * 4096:(b + 1) * 4096].astype(np.complex128)) for b in range(4)])
+    path = HERE / "fft4096.npz"
+    if check_only:
+        with np.load(path, allow_pickle=False) as z:
+            return bool(np.array_equal(z["x"], x) and np.allclose(z["y"], y, rtol=0, atol=1e-9))
+    np.savez_compressed(path, x=x, y=y)
+    print(f"fft4096.npz: 4 transforms of 4096 points ({x.size} inputs)")
+    return True
+
+
 if __name__ == "__main__":
-    main()
-
-
-# ---- fft4096.npz is NOT transcribed from the reference (it holds no vector above N = 509):
-# it is 4 transforms of the C3 stream, input from the oracle's generator (seed 0x59414749+3) and
-# output from numpy's f64 FFT, written by:
-#   x = oracle.gen_complex(0x59414749 + 3, 4 * 4096)
-#   y = [numpy.fft.fft(x[b*4096:(b+1)*4096].astype(complex128)) for b in range(4)]
-#   numpy.savez_compressed("tests/golden/fft4096.npz", x=x, y=y)
+    import sys
+    if "--fft4096" in sys.argv:
+        fft4096_definition_vectors()
+    else:
+        main()
+        fft4096_definition_vectors()

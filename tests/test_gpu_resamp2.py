@@ -220,3 +220,30 @@ def test_output_array_checks(ya):
         p.run(x, output=np.zeros(32, np.complex64)[::2])
     out = np.zeros(16, np.complex64)
     assert p.run(x, output=out) is out and out[0] == 16
+
+
+def test_device_entry_points_reject_overlapping_buffers(ya):
+    """in-place / overlapping x and y must be refused (the kernels read halos and the carried window from x
+    while other workgroups store y), with the object's state untouched"""
+    n = 4096
+    buf = ya.DeviceArray(3 * n, np.complex64)
+    buf.zero()
+    h = ya.fir_design_kaiser(31, 0.2, 60.0)
+    q = ya.FirFilter("crcf", h)
+    for xoff, yoff in ((0, 0), (0, n - 1), (n // 2, 0)):
+        with pytest.raises(ya.ConfigError):
+            q.execute_block_dev(buf.ptr + 8 * xoff, n, buf.ptr + 8 * yoff)
+    q.execute_block_dev(buf.ptr, n, buf.ptr + 8 * n)                         # adjacent is fine
+    d = ya.FirDecimationFilter("crcf", 4, h)
+    with pytest.raises(ya.ConfigError):
+        d.execute_block_dev(buf.ptr, n // 4, buf.ptr + 8 * (n - 1))         # output inside the 4n/4-sample input
+    s = ya.FirFftStream(ya.fir_design_kaiser(256, 0.2, 60.0))
+    with pytest.raises(ya.ConfigError):
+        s.execute_dev(buf.ptr, 1, buf.ptr + 8 * 100)
+    c = ya.FirPfbCh2.new_kaiser(8, 2, 60.0)
+    with pytest.raises(ya.ConfigError):
+        c.analyzer_execute_dev(buf.ptr, 64, buf.ptr + 8 * 10)
+    r = ya.Resamp2.new("crcf", 4, 0.0, 60.0)
+    with pytest.raises(ya.ConfigError):
+        r.execute_block_dev(ya.Resamp2.INTERP, buf.ptr, n, buf.ptr + 8 * (n - 1))
+    ya.synchronize()

@@ -304,3 +304,15 @@ def test_rresamp_oracle_partition(oracle, P, Q=5, m=15, n=20):
         q1.write(x[Q * n - (m - k) * Q: Q * n - (m - k - 1) * Q])
     yb = q1.execute_block(x[Q * n:], n)
     np.testing.assert_allclose(np.concatenate([ya, yb]), y0, atol=1e-12, rtol=0)
+
+
+def test_fft4096_fixture_is_reproducible():
+    """tests/golden/fft4096.npz (the N = 4096 definition vectors: no reference vector exists above N = 509) is what
+    tests/golden/make_golden.py::fft4096_definition_vectors regenerates from the repo alone"""
+    import importlib.util
+    from pathlib import Path
+    path = Path(__file__).resolve().parent / "golden" / "make_golden.py"
+    spec = importlib.util.spec_from_file_location("make_golden", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.fft4096_definition_vectors(check_only=True)

@@ -572,6 +572,16 @@ using namespace yagi;
     do {                                                                                        \
         if (!(q)) return fail(YAGI_ERR_CONFIG, "null handle");                                  \
     } while (0)
+// The block kernels read x (tile halos, the window after the block) while other workgroups already store y: an
+// in-place or overlapping call would corrupt outputs AND the carried state.  Rust's borrow rules make it unwritable in
+// the reference (&[T] and &mut [T] cannot alias); the C ABI says so explicitly.
+static int check_noalias(const void *x, size_t xbytes, const void *y, size_t ybytes) {
+    const char *a = static_cast<const char *>(x), *b = static_cast<const char *>(y);
+    if (a < b + ybytes && b < a + xbytes)
+        return fail(YAGI_ERR_CONFIG, "input and output buffers overlap (in-place execution is not supported)");
+    return YAGI_OK;
+}
+#define CHECK_NOALIAS(x, nx, y, ny) YG_TRY(check_noalias((x), (size_t)(nx) * sizeof(*(x)), (y), (size_t)(ny) * sizeof(*(y))))
 #define CHECK_PTR(p)                                                                            \
     do {                                                                                        \
         if (!(p)) return fail(YAGI_ERR_CONFIG, "null pointer argument");                        \
@@ -622,8 +632,30 @@ static int dotprod_dev(const A *a, const B *b, size_t n, O *y, hipStream_t st) {
     // user, kept for the life of the process (a per-call hipMalloc / hipFree pair costs more than the reduction of
     // 2^24 elements and forces a device synchronisation); calls on one stream are ordered, so reuse is safe there,
     // and concurrent streams of one thread are serialised by the event below
+    // One scratch per host thread AND device (hipGetDevice): the buffer and its event belong to the device that was
+    // current when they were made; after yagi_hip_set_device(other) the thread gets that device's own pair.  Released
+    // at thread exit.
     struct Scratch { void *p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
-    static thread_local Scratch sc;
+    struct PerThread {
+        std::vector<std::pair<int, Scratch>> dev;
+        ~PerThread() {
+            for (auto &e : dev) {
+                int cur = -1;
+                if (hipGetDevice(&cur) != hipSuccess) return;          // runtime already gone at process exit
+                if (hipSetDevice(e.first) != hipSuccess) continue;
+                if (e.second.done) (void)hipEventDestroy(e.second.done);
+                if (e.second.p) (void)hipFree(e.second.p);
+                (void)hipSetDevice(cur);
+            }
+        }
+    };
+    static thread_local PerThread pt;
+    int devid = 0;
+    YG_HIP(hipGetDevice(&devid));
+    Scratch *scp = nullptr;
+    for (auto &e : pt.dev) if (e.first == devid) scp = &e.second;
+    if (!scp) { pt.dev.emplace_back(devid, Scratch{}); scp = &pt.dev.back().second; }
+    Scratch &sc = *scp;
     const size_t need = np * sizeof(O);
     if (sc.done) YG_HIP(hipStreamWaitEvent(st, sc.done, 0));           // previous user of the scratch (any stream)
     else YG_HIP(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
@@ -877,6 +909,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n, y, n);                                                                  \
         return q->block_dev(x, n, y);                                                               \
     }                                                                                               \
     int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C s) {                             \
@@ -1004,6 +1037,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n * (size_t)q->M, y, n);                                                   \
         return q->block_dev(x, n, y);                                                               \
     }                                                                                               \
                                                                                                     \
@@ -1107,6 +1141,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         if (n == 0) return q->check_branch(i);                                                      \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n, y, n);                                                                  \
         return q->block_dev(i, x, n, y);                                                            \
     }                                                                                               \
     int yagi_hip_firpfb_##K##_execute_all_dev(yagi_hip_firpfb_##K q, const T *x, size_t n, T *y) {  \
@@ -1114,6 +1149,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n, y, n * (size_t)q->nf);                                                  \
         YG_TRY(q->w.flush(q->st));                                                                  \
         YG_TRY((launch_firpfb_all<KT>(q->w.dev(), x, q->taps.as<C>(), q->nf, q->Ls, q->scale, y, n, \
                                       q->st)));                                                     \
@@ -1126,6 +1162,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_PTR(idx);                                                                             \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n, y, n);                                                                  \
         YG_TRY(q->w.flush(q->st));                                                                  \
         YG_TRY((launch_firpfb_select<KT>(q->w.dev(), x, q->taps.as<C>(), idx, q->nf, q->Ls,         \
                                          q->scale, y, n, q->st)));                                  \
@@ -1395,6 +1432,7 @@ struct FirInterp {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n, y, n * (size_t)q->bank.nf);                                             \
         return q->block_dev(x, n, y);                                                               \
     }                                                                                               \
     int yagi_hip_firinterp_##K##_flush(yagi_hip_firinterp_##K q, T *y, size_t ny) {                 \
@@ -1578,6 +1616,7 @@ struct RresampObj {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, n * (size_t)q->block_len * (size_t)q->Q, y, n * (size_t)q->block_len * (size_t)q->P); \
         return q->blocks_dev(x, n * (size_t)q->block_len, y);                                       \
     }                                                                                               \
     }
@@ -2038,6 +2077,7 @@ struct FftFiltObj {
         if (nblocks == 0) return YAGI_OK;                                                           \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, nblocks * (size_t)q->n, y, nblocks * (size_t)q->n);                        \
         return q->blocks_dev(x, nblocks, y);                                                        \
     }                                                                                               \
     }
@@ -2092,6 +2132,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(spectra);
+    CHECK_NOALIAS(x, nframes * q->nfft, spectra, nframes * q->nfft);
     auto &f = q->fir;
     YG_TRY(f.w.flush(f.st));
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
@@ -2211,6 +2252,7 @@ int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const 
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    CHECK_NOALIAS(x, nframes * (size_t)q->M, y, nframes * (size_t)q->M);
     // a p == 1 channelizer has no history; the 1-sample placeholder window is never read
     bool written = false;
     cf32 *next = (q->p > 1 && q->hist.len == (int)((q->p - 1) * q->M)) ? q->hist.next() : nullptr;
@@ -2237,6 +2279,7 @@ int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, con
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    CHECK_NOALIAS(x, nframes * (size_t)q->M, y, nframes * (size_t)q->M);
     YG_TRY(launch_firpfbch_syn(q->syn_hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st));
     if (q->p > 1) return q->syn_hist.advance(x, nframes * (size_t)q->M, q->st);
     return YAGI_OK;
@@ -2319,6 +2362,7 @@ int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, c
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    CHECK_NOALIAS(x, nsteps * (size_t)q->M, y, nsteps * (size_t)(q->M / 2));
     YG_TRY(launch_firpfbch2_syn(q->syn_hist.dev(), q->syn_hist.len, x, q->h.as<float>(), q->M, q->m, q->tw.as<cf32>(),
                                 q->syn_step, y, nsteps, q->st));
     q->syn_step += nsteps;
@@ -2342,6 +2386,7 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    if (nranks > 0) CHECK_NOALIAS(x, nsteps * (size_t)(q->M / 2), y, nsteps * (size_t)(q->M / nranks));
     bool written = false;
     YG_TRY(launch_firpfbch2(q->hist.dev(), q->hist.len, x, q->h.as<float>(), q->M, q->m, q->tw.as<cf32>(),
                             q->step, rank, nranks, y, nsteps, q->st, q->hist.next(), &written));
@@ -2373,6 +2418,7 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
     CHECK_PTR(y);
+    CHECK_NOALIAS(x, nsteps * (size_t)(q->M / 2), y, nsteps * (size_t)q->M);
     const int R = comm->nranks, rank = comm->rank;
     if (R == 1 && nchunks >= 0) return yagi_hip_firpfbch2_crcf_analyzer_execute_dev(q, x, nsteps, y);
     if (q->M % R) return fail(YAGI_ERR_CONFIG, "firpfbch2: %d channels do not shard over %d ranks", q->M, R);
@@ -2690,6 +2736,7 @@ struct MsResamp2Obj {
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, nx, y, q->out_count(mode, nx));                                            \
         return q->block_dev(mode, x, nx, y);                                                        \
     }                                                                                               \
     int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
@@ -2770,6 +2817,7 @@ struct MsResamp2Obj {
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
+        CHECK_NOALIAS(x, q->interp ? n : n * q->rate, y, q->interp ? n * q->rate : n);              \
         return q->block_dev(x, n, y);                                                               \
     }                                                                                               \
     }
