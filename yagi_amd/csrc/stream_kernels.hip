@@ -210,6 +210,23 @@ static int raise_lds_limit(const void *fn, bool &done) {
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DYG_STAMPS, never the shipped library): s_memtime at the phase boundaries of every wave of the
+// MFMA FIR kernel, written to a buffer of their own (no output value depends on them): shares of a tile's time.
+#ifdef YG_STAMPS
+__device__ unsigned long long g_mfma_stamps[4096 * 4 * 8];
+#define YG_STAMP(i)                                                                                        \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        unsigned long long ts_;                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((threadIdx.x & 63u) == 0 && blockIdx.x < 4096u)                                                \
+            g_mfma_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (i)] = ts_;                        \
+    } while (0)
+#else
+#define YG_STAMP(i) do { } while (0)
+#endif
+
 template <int NS>
 __device__ __forceinline__ void load_apack(float (&a)[NS], const float *__restrict__ apack) {
     const int lane = threadIdx.x & 63;
@@ -265,29 +282,62 @@ __device__ __forceinline__ void store_task_mfma(const f32x4 (&acc)[4], float *__
         for (int r = 0; r < 4; ++r) p[2 * (16 * tt + r + tt)] = acc[tt][r] * scale;
 }
 
+// A task's accumulators straight to global memory (the plain filter: no LDS image, no barriers).  Lane (k, seg, c)
+// holds component c of the four consecutive outputs T0 + 64 seg + 16 tt + 4k + r; lanes j and j^1 (c = 0 / 1) hold
+// the real and imaginary parts of the same four outputs.  One swap between the pair turns that into two whole
+// complex samples per lane -- even lane: outputs r = 0, 1; odd lane: r = 2, 3 -- i.e. one 16-byte store per lane and
+// row tile, 128 contiguous, line-aligned bytes per (seg, tt).  `nvalid` = outputs left from o_base (tail tile).
+__device__ __forceinline__ void store_task_direct(const f32x4 (&acc)[4], float2 *__restrict__ out, size_t o_base,
+                                                  long long nvalid, int T0, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15, seg = j >> 1, c = j & 1;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const float v0 = acc[tt][0] * scale, v1 = acc[tt][1] * scale, v2 = acc[tt][2] * scale, v3 = acc[tt][3] * scale;
+        // even lane sends (re2, re3), odd lane sends (im0, im1); quad_perm [1,0,3,2] swaps neighbours
+        const float s0 = c ? v0 : v2, s1 = c ? v1 : v3;
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+        const float4 o = c ? make_float4(r0, v2, r1, v3) : make_float4(v0, r0, v1, r1);
+        const int tm = T0 + 64 * seg + 16 * tt + 4 * k + 2 * c;              // first of the lane's two outputs
+        if (tm + 1 < nvalid) *reinterpret_cast<float4 *>(out + o_base + tm) = o;
+        else if (tm < nvalid) out[o_base + tm] = make_float2(o.x, o.y);
+    }
+}
+
 // NW = waves per workgroup: 4 (two tasks per wave) or 8 (one task per wave, half the accumulators).
-template <int NS, bool FUSED, int NW>
-__global__ void __launch_bounds__(64 * NW)
+// TILE = outputs per workgroup: 4096 when FUSED (the frame); 2048 for the plain filter -- one task per wave, 16
+// accumulator registers instead of 32, so four workgroups fit a CU and a 2^24-sample block is 8 full rounds of 1024
+// workgroups (at 4096 outputs per workgroup three fit: 16 tiles per CU = 5 1/3 rounds, the last one a third full).
+template <int NS, bool FUSED, int NW, int TILE>
+__global__ void __launch_bounds__(64 * NW, (TILE == 2048 && NW == 4) ? 4 : 1)
 fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                      const float *__restrict__ apack, int L, int Lp, float scale,
-                     const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units) {
+                     const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units, bool direct) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
-    float a[NS];
-    load_apack<NS>(a, apack);
     const int wave = threadIdx.x >> 6;
-    constexpr int NT = 8 / NW;                   // tasks per wave
+    static_assert(!FUSED || TILE == kTile, "the fused form transforms whole frames");
+    constexpr int NT = TILE / 512 / NW;          // tasks per wave
+    static_assert(NT >= 1 && NT * NW * 512 == TILE, "tile = NW x NT tasks of 512 outputs");
     // FUSED: n_units = frames (tile == frame); else n_units = output samples
-    const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
-    const long long x_len = FUSED ? (long long)n_units * kTile : (long long)n_units;
+    const size_t ntiles = FUSED ? n_units : (n_units + TILE - 1) / TILE;
+    const long long x_len = FUSED ? (long long)n_units * TILE : (long long)n_units;
     {
         const size_t tile = blockIdx.x;     // one tile per workgroup, no grid-stride loop
         (void)ntiles;
-        const size_t o0 = tile * kTile;
+        const size_t o0 = tile * TILE;
+        YG_STAMP(0);
 #ifndef YG_ABL_NOSTAGE
-        stage_span(xs, win, x, (long long)o0 - (Lp - 1), kTile + Lp, L, x_len);
+        stage_span(xs, win, x, (long long)o0 - (Lp - 1), TILE + Lp, L, x_len);
 #endif
+        // the Toeplitz tap registers are requested AFTER the span (vmcnt retires in order: in front of it they would
+        // hold up the span's LDS writes) and are first needed behind the barrier
+        float a[NS];
+        load_apack<NS>(a, apack);
+        YG_STAMP(1);
         __syncthreads();
+        YG_STAMP(2);
         f32x4 acc[NT][4];
 #ifndef YG_ABL_NOMFMA
 #pragma unroll
@@ -299,11 +349,21 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{a[q], a[q + 4], xs[threadIdx.x + q].x, 0.f};
 #endif
+        YG_STAMP(3);
+        if (!FUSED && direct) {                  // plain filter, 16-byte aligned output: registers -> HBM
+            const long long nvalid = (long long)(n_units - o0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) store_task_direct(acc[t], out, o0, nvalid, 512 * (wave + NW * t), scale);
+            YG_STAMP(6);
+            return;
+        }
         __syncthreads();                         // all waves done reading the span: reuse it as output image
+        YG_STAMP(4);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             store_task_mfma(acc[t], reinterpret_cast<float *>(xs), 512 * (wave + NW * t), scale);
         __syncthreads();
+        YG_STAMP(5);
         if (FUSED) {
             const bool active = (NW == 4) || threadIdx.x < 256;
             float2 v[16];
@@ -314,11 +374,16 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
             __syncthreads();
             fft4096_passes<-1, (NW > 4), YG_FUSED_TWP>(v, xs, tw, out + o0);
         } else {
-            const int nt = (int)((n_units - o0) < (size_t)kTile ? (n_units - o0) : (size_t)kTile);
+            const int nt = (int)((n_units - o0) < (size_t)TILE ? (n_units - o0) : (size_t)TILE);
 #ifndef YG_ABL_NOSTORE
             for (int o = threadIdx.x; o < nt; o += 64 * NW) out[o0 + o] = xs[padded(o)];
 #else
             if (xs[padded(threadIdx.x)].x == 123.456f) out[o0 + threadIdx.x] = xs[padded(threadIdx.x)];
+#endif
+            YG_STAMP(6);
+#ifdef YG_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            YG_STAMP(7);
 #endif
             __syncthreads();
         }
@@ -338,17 +403,23 @@ void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack) {
         }
 }
 
+#ifndef YG_MFMA_TILE
+#define YG_MFMA_TILE 2048
+#endif
 template <int NS, bool FUSED, int NW>
 static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
                          const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
+    constexpr int TILE = FUSED ? kTile : YG_MFMA_TILE;
     static bool raised = false;
-    YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW>), raised));
-    const size_t ntiles = FUSED ? n_units : (n_units + kTile - 1) / kTile;
+    YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW, TILE>), raised));
+    const size_t ntiles = FUSED ? n_units : (n_units + TILE - 1) / TILE;
     if (ntiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const unsigned grid = (unsigned)ntiles;
-    fir_crcf_mfma_kernel<NS, FUSED, NW><<<grid, 64 * NW, slide_lds_bytes(Lp), st>>>(
+    const size_t lds = FUSED ? slide_lds_bytes(Lp) : (size_t)((TILE + Lp) >> 4) * kRowPad * sizeof(float2);
+    fir_crcf_mfma_kernel<NS, FUSED, NW, TILE><<<grid, 64 * NW, lds, st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, Lp, scale,
-        reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units);
+        reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units,
+        !FUSED && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -558,3 +629,9 @@ int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pa
 }
 
 }  // namespace yagi
+
+#ifdef YG_STAMPS
+extern "C" int yagi_hip_debug_mfma_stamps(unsigned long long *dst, size_t count) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(yagi::g_mfma_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
