@@ -19,7 +19,15 @@ ya.gen_complex_dev(0x59414749 + 2, n, out=x, stream=st.cuda_stream)
 h = ya.fir_design_kaiser(256, 0.2, 60.0)
 keep = []
 for w in what:
-    if w in ("fused", "fused2", "fused3", "fused4"):
+    if w == "stream16":      # the bench.py step: 16 distinct 2^24-sample blocks (nothing Infinity-Cache resident)
+        xb = torch.empty(16 * n, dtype=torch.complex64, device=dev)
+        yb = torch.empty(16 * n, dtype=torch.complex64, device=dev)
+        ya.gen_complex_dev(0x59414749 + 2, 16 * n, out=xb, stream=st.cuda_stream)
+        f = ya.FirFftStream(h); f.set_scale(0.4); f.set_stream(st.cuda_stream)
+        def fn(f=f, xb=xb, yb=yb):
+            for b in range(16):
+                f.execute_dev(xb.data_ptr() + 8 * n * b, n // 4096, yb.data_ptr() + 8 * n * b)
+    elif w in ("fused", "fused2", "fused3", "fused4"):
         f = ya.FirFftStream(h); f.set_stream(st.cuda_stream); f.set_variant({"fused": 1, "fused2": 2, "fused3": 3, "fused4": 4}[w])
         fn = lambda f=f: f.execute_dev(x, n // 4096, y)
     elif w in ("fir1", "fir2", "fir3", "fir4"):

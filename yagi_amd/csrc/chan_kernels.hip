@@ -757,6 +757,20 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifdef YG_STAMPS
+__device__ unsigned long long g_chan_stamps[2048 * 4 * 12];
+#define YG_CSTAMP(i)                                                                                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        unsigned long long ts_;                                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((threadIdx.x & 63u) == 0 && blockIdx.x < 2048u && t == 2 * kColTile)                         \
+            g_chan_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 12u + (i)] = ts_;                      \
+    } while (0)
+#else
+#define YG_CSTAMP(i) do { } while (0)
+#endif
 // firpfbch2, column-sliding form (M in {64,128,256}, branch length P = 2m in {2,4,8}, even first step):
 // lane b owns window b.  A window is fed once per PAIR of steps (even steps feed b < M/2, odd steps feed
 // b >= M/2) and produces an output on both steps of the pair with two different tap sets
@@ -824,6 +838,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     float2 *yb = y + wg_first * Mr;
     auto half_tile = [&](float2 (&xin)[kPairs], int t, auto slot0) {
         constexpr int S0 = decltype(slot0)::value;                       // ring slot of the half tile's first pair
+        YG_CSTAMP(0);
 #pragma unroll
         for (int kk = 0; kk < kPairs; ++kk) {
             const float2 old = w[(S0 + kk) % P];
@@ -847,7 +862,9 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             va[(g * kColHalf + 2 * kk + 1) * pitch + b] = a1;
         }
         if (t + kColTile < run) load4(xin, t + kColTile);                 // in flight during the transforms
+        YG_CSTAMP(1);
         __syncthreads();
+        YG_CSTAMP(2);
         const float2 *res;
         if constexpr (SHARDED) {
             // fold to the rank's residue class: Z[b'] = W_M^{-b' r} sum_a W_R^{-a r} V[Mr*a + b']
@@ -867,11 +884,26 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             res = lds_fft_pow2<+1, true>(vb, va, Mr, nq, plan, twl, R, true, pitch, lgnq);
         } else {
             stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+            YG_CSTAMP(3);
             __syncthreads();
+            YG_CSTAMP(4);
             res = vb;
-            if constexpr (R1 > 1) {
+            if constexpr (R1 >= 8 && M / R1 >= 16) {
+                // last pass straight from registers to y: 16-lane runs of 128 contiguous bytes (M = 256)
+                stockham_last_pass_out<R1, +1>(vb, M, nq, twl, 1, true, pitch, [&](int q, int k, float2 v) {
+                    const int gq = q / kColHalf, sr = t + (q - gq * kColHalf);
+                    if (full || sr < group_steps(gq))
+                        yb[(size_t)(gq * run + sr) * M + k] = make_float2(v.x * invM, v.y * invM);
+                });
+                YG_CSTAMP(7);
+                YG_CSTAMP(8);
+                return;                          // no barrier: the next half tile writes va first, and its own
+                                                 // barrier stands between this pass's reads of vb and the next writes
+            } else if constexpr (R1 > 1) {
                 stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+                YG_CSTAMP(5);
                 __syncthreads();
+                YG_CSTAMP(6);
                 res = va;
             }
         }
@@ -883,7 +915,9 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                 yb[(size_t)(gq * run + sr) * Mr + k] = make_float2(v.x * invM, v.y * invM);
             }
         }
+        YG_CSTAMP(7);
         __syncthreads();
+        YG_CSTAMP(8);
     };
     load4(xa, 0);
     load4(xb, kColHalf);
@@ -1236,3 +1270,9 @@ int launch_firpfbch2_assemble(const cf32 *gathered, size_t nsteps, int M, int nr
 }
 
 }  // namespace yagi
+
+#ifdef YG_STAMPS
+extern "C" int yagi_hip_debug_chan_stamps(unsigned long long *dst, size_t count) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(yagi::g_chan_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

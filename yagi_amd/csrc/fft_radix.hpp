@@ -134,6 +134,35 @@ __device__ __forceinline__ void stockham_pass(const float2 *__restrict__ src, fl
     }
 }
 
+// The LAST pass (Ns R = N) with its outputs handed to `out(fr, k, value)` from registers instead of going back to LDS:
+// lanes butterfly-fastest, so for every q the T = N/R lanes of a transform deliver T consecutive bins k = j + q T
+// (a 128-byte run of a [frame][channel] row at T = 16).  Saves the pass's LDS writes, the barrier behind them and the
+// read-back of the store loop.  Reads: s[r T] with consecutive j -> conflict-free within a transform.
+template <int R, int SIGN, class Out>
+__device__ __forceinline__ void stockham_last_pass_out(const float2 *__restrict__ src, int N, int nfr,
+                                                       const float2 *__restrict__ twl, int tw_scale,
+                                                       bool tw_is_forward, int pitch, Out out) {
+    const int T = N / R;                                   // = Ns of the last pass: k = j
+    const int lgT = 31 - __builtin_clz((unsigned)T);
+    const int total = T * nfr;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int fr = e >> lgT, j = e & (T - 1);
+        const float2 *s = src + fr * pitch + j;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = s[r * T];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            float2 w = twl[j * r * tw_scale];
+            if (SIGN > 0 && tw_is_forward) w.y = -w.y;
+            v[r] = cmul(v[r], w);
+        }
+        dftR<R, SIGN>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) out(fr, j + q * T, v[dftR_pos<R>(q)]);
+    }
+}
+
 // radix plan for N = 2^lg: the fewest passes radix <= 16 allows (ceil(lg/4)), with the bits spread evenly over
 // them (64 = 8 x 8 rather than 16 x 4: every pass then has N/8 butterflies per transform, so short transforms
 // keep all lanes of the workgroup busy in every pass)
