@@ -362,7 +362,7 @@ static int make_twiddles(int n, int dir, DevBuf &buf, bool half_too = false) {
 }
 
 // twiddle table of the 4096-point stream kernels: W_4096^m (m < 4096, forward) followed by six 256-entry rows the
-// frequency-domain kernel reads with the lane index (coalesced, no gathers): rows 0-3 W^{t 2^k}, row 4 W^{(t&15)(t>>4)},
+// frequency-domain kernels read with the lane index (coalesced, no gathers): rows 0-3 W^{t 2^k}, row 4 W^{(t&15)(t>>4)},
 // row 5 W_256^{(t&15)(t>>4)}
 static int make_stream_twiddles(DevBuf &buf) {
     std::vector<cf32> tab(4096 + 6 * 256);

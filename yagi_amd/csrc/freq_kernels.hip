@@ -49,7 +49,9 @@ namespace yagi {
 // frame's loads prefetched (static split 68 us, ticket counter 81 us: one counter word saturates at ~90 tickets
 // per us), the corrections of a block as a launch of their own (15 + 58 us), FFT{h} / twiddle loads hoisted to
 // the kernel head (no change; with FFT{h} in registers from the start: spills), the correction transform's two
-// output factors as one gathered table entry (+12 %: the gathers again).
+// output factors as one gathered table entry (+12 %: the gathers again), and a two-wave workgroup per frame (main wave:
+// 64 x 64 transform of the frame in one wave's registers; correction wave: sum + transform of c_f; spectra added through
+// LDS; two barriers per frame): 78.6 us -- at 2 waves per SIMD the long dependent chains are not hidden.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFreqMaxTaps = 257;
 constexpr unsigned kOffCvs = kFft4096LdsFloat2;          // c_f, 256 float2 (behind the exchange buffer)
