@@ -137,14 +137,15 @@ def test_fft_large_batch_on_device(ya, oracle, n):
         assert rel_l2(dy.to_numpy(n, offset=b * n), truth) <= 1e-5, b
 
 
-@pytest.mark.parametrize("n", [16384, 32768, 65536, 1 << 17, 1 << 20, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4])
+@pytest.mark.parametrize("n", [16384, 32768, 65536, 1 << 17, 1 << 20, 1 << 22, 1 << 24, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4])
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_beyond_one_workgroup(ya, n, direction):
-    """n > 8192: 2^14 .. 2^16 by the two-launch column / row form (no transposes), larger powers of two and smooth
+    """n > 8192: 2^14 and 2^15 by the two-launch column / row form over the LDS core, powers of two from 2^16 up as
+    256 x n2 (256-point columns in registers, then the n2-point rows: two launches at 2^16, three above), smooth
     sizes by the four-step form (transposes around the register kernels), every other size by Bluestein over a
     power of two.  Truth: numpy's f64 FFT of the same f32 samples."""
     rng = np.random.default_rng(n)
-    batch = 2
+    batch = 2 if n < (1 << 22) else 1
     x = ((rng.standard_normal(batch * n) + 1j * rng.standard_normal(batch * n)) * np.sqrt(0.5)).astype(np.complex64)
     d = ya.Direction[direction]
     got = ya.Fft(n, d).run_batch(x)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """FFT size sweep (GPU box): sustained time of Fft::run over 2^24 points for each size."""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -7,7 +8,7 @@ import numpy as np
 import torch
 import yagi_amd as ya
 
-n = 1 << 24
+n = 1 << int(os.environ.get("KB_TOTAL_LOG2", "24"))      # points per run
 dev = torch.device("cuda")
 x = torch.empty(n, dtype=torch.complex64, device=dev)
 y = torch.empty(n, dtype=torch.complex64, device=dev)

@@ -325,7 +325,7 @@ struct FftPlan {
     DevBuf bs_w, bs_bf, bs_twf, bs_twb, bs_scratch;      // Bluestein resources (sizes with a large prime factor)
     std::unique_ptr<FftPlan> bs_fwd, bs_bwd;             // Bluestein over m > 8192: the m-point plans
     std::unique_ptr<FftPlan> fs_p1, fs_p2;               // four-step: the n1- and n2-point plans
-    DevBuf fs_scratch, fs_wn;
+    DevBuf fs_scratch, fs_wn, fs_wsplit;
 };
 
 // radix list of the mixed-radix kernel: the power of two in as few passes as radix <= 16 allows (bits spread
@@ -394,6 +394,39 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
         // four-step: n = n1 n2, both <= 8192, as balanced as the divisors of n allow, and neither with a prime factor
         // that would send it to Bluestein (> 89); a size without such a split (a large prime factor) takes Bluestein
         size_t n2 = 0;
+        if (pow2 && n >= 65536) {
+            // n = 256 n2: 256-point columns in registers, then the n2-point rows (fft_kernels.hip: fft_tile256_kernel)
+            n2 = n / 256;
+            p.fs_p1 = std::make_unique<FftPlan>();
+            p.fs_p2 = std::make_unique<FftPlan>();
+            YG_TRY(fft_plan_init(*p.fs_p1, 256, dir));
+            YG_TRY(fft_plan_init(*p.fs_p2, n2, dir));
+            size_t chunk = ((size_t)1 << 23) / n;              // 64 MiB per scratch buffer (smaller chunks measured slower)
+            if (chunk < 1) chunk = 1;
+            YG_TRY(p.fs_scratch.alloc((n2 == 256 ? 1 : 2) * chunk * n * sizeof(cf32)));
+            const size_t nhi = n / 4096;
+            std::vector<cf32> tab(4096 + nhi);
+            const double s = dir == YAGI_FFT_FORWARD ? -1.0 : 1.0;
+            for (size_t j = 0; j < 4096; ++j) {
+                const double a = s * 2.0 * M_PI * (double)j / (double)n;
+                tab[j] = cf32{(float)std::cos(a), (float)std::sin(a)};
+            }
+            for (size_t j = 0; j < nhi; ++j) {
+                const double a = s * 2.0 * M_PI * (double)j / (double)nhi;
+                tab[4096 + j] = cf32{(float)std::cos(a), (float)std::sin(a)};
+            }
+            YG_TRY(p.fs_wsplit.alloc(tab.size() * sizeof(cf32)));
+            YG_TRY(upload(p.fs_wsplit.p, tab.data(), tab.size() * sizeof(cf32), nullptr));
+            p.d.fs_n1 = 256;
+            p.d.fs_n2 = (int)n2;
+            p.d.fs_p1 = &p.fs_p1->d;
+            p.d.fs_p2 = &p.fs_p2->d;
+            p.d.fs_scratch = p.fs_scratch.as<cf32>();
+            p.d.fs_chunk = (int)chunk;
+            p.d.fs_wlo = p.fs_wsplit.as<cf32>();
+            p.d.fs_whi = p.fs_wsplit.as<cf32>() + 4096;
+            return YAGI_OK;
+        }
         auto smooth = [](size_t v) {
             for (size_t q = 2; q <= 89 && v > 1; ++q) while (v % q == 0) v /= q;
             return v == 1;

@@ -347,6 +347,110 @@ static int launch_fft_two_pass(const FftPlanDev &p, const cf32 *in, cf32 *out, s
     return YAGI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Powers of two from 2^16 up: n = 256 n2 viewed as x[256][n2], the 256-point factor in registers
+// (fft_n256m_passes_to_regs<SIGN, 1>), 16 transforms per workgroup, every global access a 128-byte run.
+//   MODE 0 (columns): columns c0..c0+15 come in as 256 rows of 16 consecutive points, are turned through LDS into
+//           the register layout, transformed, multiplied by W_n^{c k1} and written back the same way:
+//           S[k1][c] = W_n^{k1 c} FFT_256{x[.][c]}[k1]
+//   MODE 1 (rows, n2 = 256 only): rows k1_0..k1_0+15 of S are contiguous; their transforms leave transposed,
+//           X[k2 * 256 + k1], again as runs of 16 points.
+// For n2 > 256 the rows go through the n2-point plan and one tiled transposition (launch_fft_tile256).
+// W_n^m comes from two exact tables (the lane needs five powers, the rest are products):
+//   W_n^m = whi[m >> 12] * wlo[m & 4095],  wlo[j] = W_n^j, whi[j] = W_n^{4096 j}
+// The column pass runs at what a read-HBM / write kernel reaches here (4.4 TB/s; prefetching the next tile's samples
+// into registers, contiguous instead of strided rows and dropping the twiddles each changed nothing: r02_notes.md);
+// the row pass reads what the column pass just wrote (Infinity Cache) and runs at 6.2 TB/s.
+// Staging pitch 258 float2: the 16-column side of the exchange is conflict free, the transform side two-way.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTilePitch = 258;
+static_assert(16 * kTilePitch <= kFft4096LdsFloat2, "staging fits the exchange buffer");
+
+__device__ __forceinline__ float2 wn_split(const float2 *__restrict__ wlo, const float2 *__restrict__ whi, unsigned m) {
+    return cmul(whi[m >> 12], wlo[m & 4095u]);
+}
+
+template <int SIGN, int MODE>
+__global__ void __launch_bounds__(256)
+fft_tile256_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw256,
+                   const float2 *__restrict__ wlo, const float2 *__restrict__ whi, int n2) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x, tr = t >> 4, u = t & 15u;    // register layout: transform tr, lane u
+    const unsigned col = t & 15u, r = t >> 4;                    // tile layout: 16 points of row r + 16 it
+    const size_t mat = (size_t)blockIdx.y * 256 * (size_t)n2;
+    const unsigned c0 = blockIdx.x * 16;
+    float2 v[16];
+    if (MODE == 0) {
+        const float2 *src = in + mat + c0 + col + (size_t)r * n2;
+        float2 s[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) s[it] = src[(size_t)(16 * it) * n2];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) lds[col * kTilePitch + r + 16 * it] = s[it];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = lds[tr * kTilePitch + 16 * a + u];
+        __syncthreads();
+    } else {
+        const float2 *src = in + mat + (size_t)(c0 + tr) * 256 + u;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = src[16 * a];
+    }
+    fft_n256m_passes_to_regs<SIGN, 1>(v, lds, tw256);             // v[i] = X[u + 16 i]
+    if (MODE == 0) {
+        const unsigned c = c0 + tr;                               // exponents c (u + 16 i) < n: no wrap
+        float2 w[16];
+        twiddle_powers_from(w, wn_split(wlo, whi, 16u * c), wn_split(wlo, whi, 32u * c), wn_split(wlo, whi, 64u * c),
+                            wn_split(wlo, whi, 128u * c));
+        const float2 e0 = wn_split(wlo, whi, c * u);
+        v[0] = cmul(v[0], e0);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v[i] = cmul(v[i], cmul(w[i], e0));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds[tr * kTilePitch + u + 16 * i] = v[i];
+    __syncthreads();
+    const size_t pitch = MODE == 0 ? (size_t)n2 : 256;
+    float2 *dst = out + mat + c0 + col + (size_t)r * pitch;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) dst[(size_t)(16 * it) * pitch] = lds[col * kTilePitch + r + 16 * it];
+}
+
+template <int MODE>
+static void launch_tile256(bool fwd, dim3 grid, const float2 *in, float2 *out, const float2 *tw256, const float2 *wlo,
+                           const float2 *whi, int n2, hipStream_t st) {
+    if (fwd) fft_tile256_kernel<-1, MODE><<<grid, 256, 0, st>>>(in, out, tw256, wlo, whi, n2);
+    else fft_tile256_kernel<+1, MODE><<<grid, 256, 0, st>>>(in, out, tw256, wlo, whi, n2);
+}
+
+static int launch_fft_tile256(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    const int n2 = p.fs_n2;
+    const size_t n = (size_t)p.n;
+    const FftPlanDev &f1 = *p.fs_p1, &f2 = *p.fs_p2;
+    float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch), *s1 = s0 + (size_t)p.fs_chunk * n;
+    const float2 *tw256 = reinterpret_cast<const float2 *>(f1.tw);
+    const float2 *wlo = reinterpret_cast<const float2 *>(p.fs_wlo), *whi = reinterpret_cast<const float2 *>(p.fs_whi);
+    const bool fwd = p.dir == YAGI_FFT_FORWARD;
+    for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.fs_chunk) {
+        const unsigned nb = (unsigned)((batch - b0) < (size_t)p.fs_chunk ? (batch - b0) : (size_t)p.fs_chunk);
+        const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
+        float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
+        launch_tile256<0>(fwd, dim3((unsigned)(n2 / 16), nb), src, s0, tw256, wlo, whi, n2, st);
+        YG_LAUNCH_CHECK();
+        if (n2 == 256) {
+            launch_tile256<1>(fwd, dim3(16, nb), s0, dst, tw256, wlo, whi, n2, st);
+            YG_LAUNCH_CHECK();
+        } else {
+            YG_TRY(launch_fft_batch(f2, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * 256, st));
+            // D[k1][k2] -> X[k2][k1]
+            fft_transpose_kernel<false><<<dim3((unsigned)(n2 / 32), 8, nb), 256, 0, st>>>(s1, dst, 256, n2, 0.0);
+            YG_LAUNCH_CHECK();
+        }
+    }
+    return YAGI_OK;
+}
+
 static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int n1 = p.fs_n1, n2 = p.fs_n2;
     const size_t n = (size_t)p.n;
@@ -420,6 +524,7 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
         return YAGI_OK;
     }
     if (p.bs_m) return launch_fft_bluestein(p, in, out, batch, st);
+    if (p.fs_n1 && p.fs_wlo) return launch_fft_tile256(p, in, out, batch, st);
     if (p.fs_n1 && p.fs_wn) return launch_fft_two_pass(p, in, out, batch, st);
     if (p.fs_n1) return launch_fft_four_step(p, in, out, batch, st);
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_INTERNAL, "fft size %d has no plan resources", p.n);

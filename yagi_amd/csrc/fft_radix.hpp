@@ -299,14 +299,19 @@ __device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2
         for (int a = 0; a < 16; ++a) v[a] = e1[M * a];
         __syncthreads();                                         // exchange-1 reads done before the buffer is reused
         dft16<SIGN>(v);
-        float2 w[16];
-        twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));      // W_{16M}^{b' c'} = W_N^{16 b' c'}
         float2 *e2 = lds + tr * T2 + bp * S2 + c;
+        if constexpr (M == 1) {                                  // b' = 0: every twiddle of this pass is 1
 #pragma unroll
-        for (int cp = 0; cp < 16; ++cp) {
-            float2 z = v[dft16_pos(cp)];
-            if (cp) z = cmul(z, w[cp]);
-            e2[16 * cp] = z;
+            for (int cp = 0; cp < 16; ++cp) e2[16 * cp] = v[dft16_pos(cp)];
+        } else {
+            float2 w[16];
+            twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));  // W_{16M}^{b' c'} = W_N^{16 b' c'}
+#pragma unroll
+            for (int cp = 0; cp < 16; ++cp) {
+                float2 z = v[dft16_pos(cp)];
+                if (cp) z = cmul(z, w[cp]);
+                e2[16 * cp] = z;
+            }
         }
     }
     __syncthreads();
