@@ -371,10 +371,13 @@ def test_firpfbch_analysis_synthesis_round_trip(ya, M, p):
     assert rel_l2(y, M * x.astype(np.complex128)) <= 2e-6
 
 
-@pytest.mark.parametrize("M,m,ns", [(4, 1, 40), (8, 2, 101), (16, 4, 64), (64, 3, 50), (6, 2, 33), (10, 1, 50), (256, 2, 21)])
+@pytest.mark.parametrize("M,m,ns", [(4, 1, 40), (8, 2, 101), (16, 4, 64), (64, 3, 50), (6, 2, 33), (10, 1, 50), (256, 2, 21),
+                                    (8, 2, 300), (16, 4, 257), (32, 2, 211), (64, 4, 230), (128, 2, 200), (256, 4, 215)])
 def test_firpfbch2_synthesizer_vs_oracle(ya, oracle, M, m, ns):
     """firpfbch2 synthesizer (PARITY UNPINNED) against the step-by-step restatement; odd splits carry the
-    step parity and the window across calls; independent of the analyzer's state"""
+    step parity and the window across calls; independent of the analyzer's state.  Calls of >= 64 steps with M a power
+    of two in 8 .. 256 and m in {2, 4} run the column-sliding kernel (the last six cases: first and third call), the
+    rest the tiled one."""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
     h = (h * M / h.sum()).astype(np.float32)
     X = oracle.gen_complex(SEED + 10, ns * M)

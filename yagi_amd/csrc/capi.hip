@@ -623,35 +623,35 @@ static int check_noalias(const void *x, size_t xbytes, const void *y, size_t yby
 extern "C" {
 
 // ---- device plumbing ------------------------------------------------------------------------
-int yagi_hip_device_count(int *count) {
+int yagi_hip_device_count(int *count) try {
     CHECK_PTR(count);
     *count = 0;
     hipError_t e = hipGetDeviceCount(count);
     if (e != hipSuccess) { *count = 0; return fail(YAGI_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     return YAGI_OK;
-}
-int yagi_hip_set_device(int device) { YG_HIP(hipSetDevice(device)); return YAGI_OK; }
-int yagi_hip_malloc(void **p, size_t bytes) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_set_device(int device) try { YG_HIP(hipSetDevice(device)); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_malloc(void **p, size_t bytes) try {
     CHECK_PTR(p);
     YG_TRY(require_device());
     YG_HIP(hipMalloc(p, bytes ? bytes : 16));
     return YAGI_OK;
-}
-int yagi_hip_free(void *p) { if (p) YG_HIP(hipFree(p)); return YAGI_OK; }
-int yagi_hip_memcpy_h2d(void *d, const void *s, size_t n) { YG_HIP(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return YAGI_OK; }
-int yagi_hip_memcpy_d2h(void *d, const void *s, size_t n) { YG_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return YAGI_OK; }
-int yagi_hip_memset_dev(void *d, int v, size_t n) { YG_HIP(hipMemset(d, v, n)); return YAGI_OK; }
-int yagi_hip_device_synchronize(void) { YG_HIP(hipDeviceSynchronize()); return YAGI_OK; }
-int yagi_hip_stream_synchronize(yagi_stream_t s) { YG_HIP(hipStreamSynchronize(to_stream(s))); return YAGI_OK; }
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_free(void *p) try { if (p) YG_HIP(hipFree(p)); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_memcpy_h2d(void *d, const void *s, size_t n) try { YG_HIP(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_memcpy_d2h(void *d, const void *s, size_t n) try { YG_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_memset_dev(void *d, int v, size_t n) try { YG_HIP(hipMemset(d, v, n)); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_device_synchronize(void) try { YG_HIP(hipDeviceSynchronize()); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_stream_synchronize(yagi_stream_t s) try { YG_HIP(hipStreamSynchronize(to_stream(s))); return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_gen_real_dev(uint64_t seed, uint64_t first, size_t n, float *x, yagi_stream_t s) {
+int yagi_hip_gen_real_dev(uint64_t seed, uint64_t first, size_t n, float *x, yagi_stream_t s) try {
     YG_TRY(require_device());
     return launch_gen_real(seed, first, n, x, to_stream(s));
-}
-int yagi_hip_gen_complex_dev(uint64_t seed, uint64_t first, size_t n, yagi_cf32 *x, yagi_stream_t s) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_gen_complex_dev(uint64_t seed, uint64_t first, size_t n, yagi_cf32 *x, yagi_stream_t s) try {
     YG_TRY(require_device());
     return launch_gen_complex(seed, first, n, x, to_stream(s));
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 }  // extern "C"
 
@@ -717,14 +717,14 @@ static int dotprod_host(const A *a, const B *b, size_t n, O *y) {
 }
 
 extern "C" {
-int yagi_hip_dotprod_rrrf(const float *a, const float *b, size_t n, float *y) { return dotprod_host<float, float, float>(a, b, n, y); }
-int yagi_hip_dotprod_rccf(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) { return dotprod_host<float, cf32, cf32>(a, b, n, y); }
-int yagi_hip_dotprod_crcf(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y) { return dotprod_host<cf32, float, cf32>(a, b, n, y); }
-int yagi_hip_dotprod_cccf(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) { return dotprod_host<cf32, cf32, cf32>(a, b, n, y); }
-int yagi_hip_dotprod_rrrf_dev(const float *a, const float *b, size_t n, float *y, yagi_stream_t s) { return dotprod_dev<float, float, float>(a, b, n, y, to_stream(s)); }
-int yagi_hip_dotprod_rccf_dev(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<float, cf32, cf32>(a, b, n, y, to_stream(s)); }
-int yagi_hip_dotprod_crcf_dev(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<cf32, float, cf32>(a, b, n, y, to_stream(s)); }
-int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) { return dotprod_dev<cf32, cf32, cf32>(a, b, n, y, to_stream(s)); }
+int yagi_hip_dotprod_rrrf(const float *a, const float *b, size_t n, float *y) try { return dotprod_host<float, float, float>(a, b, n, y); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_rccf(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) try { return dotprod_host<float, cf32, cf32>(a, b, n, y); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_crcf(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y) try { return dotprod_host<cf32, float, cf32>(a, b, n, y); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_cccf(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y) try { return dotprod_host<cf32, cf32, cf32>(a, b, n, y); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_rrrf_dev(const float *a, const float *b, size_t n, float *y, yagi_stream_t s) try { return dotprod_dev<float, float, float>(a, b, n, y, to_stream(s)); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_rccf_dev(const float *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) try { return dotprod_dev<float, cf32, cf32>(a, b, n, y, to_stream(s)); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_crcf_dev(const yagi_cf32 *a, const float *b, size_t n, yagi_cf32 *y, yagi_stream_t s) try { return dotprod_dev<cf32, float, cf32>(a, b, n, y, to_stream(s)); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, yagi_cf32 *y, yagi_stream_t s) try { return dotprod_dev<cf32, cf32, cf32>(a, b, n, y, to_stream(s)); } catch (...) { return ::yagi::api_exception(); }
 }
 
 // ---- FIR family: generic bodies, instantiated per type combination by YAGI_FIR_IMPL ----------------
@@ -829,7 +829,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     struct yagi_hip_firdecim_##K##_s : FirDecim<KT> {};                                             \
     struct yagi_hip_firpfb_##K##_s : FirPfb<KT> {};                                                 \
     extern "C" {                                                                                    \
-    int yagi_hip_firfilt_##K##_create(const C *h, size_t h_len, yagi_hip_firfilt_##K *q) {          \
+    int yagi_hip_firfilt_##K##_create(const C *h, size_t h_len, yagi_hip_firfilt_##K *q) try {      \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -837,9 +837,9 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->init(h, h_len));                                                                  \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_create_kaiser(size_t n, float fc, float as_, float mu,               \
-                                             yagi_hip_firfilt_##K *q) {                             \
+                                             yagi_hip_firfilt_##K *q) try {                         \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         std::vector<float> hf;                                                                      \
@@ -847,22 +847,22 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         std::vector<C> hc(hf.size());                                                               \
         for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_create_rect(size_t n, yagi_hip_firfilt_##K *q) {                     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_create_rect(size_t n, yagi_hip_firfilt_##K *q) try {                 \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (n == 0 || n > 1024) return fail(YAGI_ERR_CONFIG, "filter length must be in [1,1024]");  \
         std::vector<C> hc(n, one_of<C>());                                                          \
         return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_create_notch(size_t m, float as_, float f0, yagi_hip_firfilt_##K *q) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_create_notch(size_t m, float as_, float f0, yagi_hip_firfilt_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         std::vector<C> hc;                                                                          \
         YG_TRY(notch_taps(m, as_, f0, hc));                                                         \
         return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_create_dc_blocker(size_t m, float as_, yagi_hip_firfilt_##K *q) {    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_create_dc_blocker(size_t m, float as_, yagi_hip_firfilt_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         std::vector<float> hf;                                                                      \
@@ -870,12 +870,12 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         std::vector<C> hc(hf.size());                                                               \
         for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firfilt_##K##_create(hc.data(), hc.size(), q);                              \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q) {                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_destroy(yagi_hip_firfilt_##K q) try {                                \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_clone(yagi_hip_firfilt_##K q, yagi_hip_firfilt_##K *out) {           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_clone(yagi_hip_firfilt_##K q, yagi_hip_firfilt_##K *out) try {       \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -888,15 +888,15 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s) try {            \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_set_coefficients(yagi_hip_firfilt_##K q, const C *h, size_t n) {     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_set_coefficients(yagi_hip_firfilt_##K q, const C *h, size_t n) try { \
         CHECK_Q(q);                                                                                 \
         if (n && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
@@ -904,85 +904,85 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(q->load_taps(h, n));                                                                 \
         if (resize) return q->w.init(q->L, q->st);                                                  \
         return q->w.reset(q->st);                                                                   \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_reset(yagi_hip_firfilt_##K q) {                                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_reset(yagi_hip_firfilt_##K q) try {                                  \
         CHECK_Q(q);                                                                                 \
         return q->w.reset(q->st);                                                                   \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_push(yagi_hip_firfilt_##K q, T x) {                                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_push(yagi_hip_firfilt_##K q, T x) try {                              \
         CHECK_Q(q);                                                                                 \
         q->w.push(x);                                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_write(yagi_hip_firfilt_##K q, const T *x, size_t n) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_write(yagi_hip_firfilt_##K q, const T *x, size_t n) try {            \
         CHECK_Q(q);                                                                                 \
         if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
         for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_execute(yagi_hip_firfilt_##K q, T *y) {                              \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_execute(yagi_hip_firfilt_##K q, T *y) try {                          \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(y);                                                                               \
         YG_TRY(q->w.flush(q->st));                                                                  \
         return window_dot<KT>(q->w.dev(), q->taps.as<C>(), q->L, q->scale, q->ws, y, q->st);        \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_execute_one(yagi_hip_firfilt_##K q, T x, T *y) {                     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_execute_one(yagi_hip_firfilt_##K q, T x, T *y) try {                 \
         CHECK_Q(q);                                                                                 \
         q->w.push(x);                                                                               \
         return yagi_hip_firfilt_##K##_execute(q, y);                                                \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_execute_block(yagi_hip_firfilt_##K q, const T *x, size_t nx, T *y,   \
-                                             size_t ny) {                                           \
+                                             size_t ny) try {                                       \
         CHECK_Q(q);                                                                                 \
         return firfilt_block_host<KT>(q, x, nx, y, ny);                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_execute_block_dev(yagi_hip_firfilt_##K q, const T *x, size_t n,      \
-                                                 T *y) {                                            \
+                                                 T *y) try {                                        \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n, y, n);                                                                  \
         return q->block_dev(x, n, y);                                                               \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C s) {                             \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C s) try {                         \
         CHECK_Q(q);                                                                                 \
         q->scale = s;                                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *s) {                            \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *s) try {                        \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(s);                                                                               \
         *s = q->scale;                                                                              \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *n) {                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *n) try {                  \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(n);                                                                               \
         *n = (size_t)q->L;                                                                          \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_get_coefficients(yagi_hip_firfilt_##K q, C *h, size_t n) {           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_get_coefficients(yagi_hip_firfilt_##K q, C *h, size_t n) try {       \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(h);                                                                               \
         if (n < (size_t)q->L) return fail(YAGI_ERR_CONFIG, "coefficient buffer too short");         \
         std::memcpy(h, q->h.data(), (size_t)q->L * sizeof(C));                                      \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_freqresponse(yagi_hip_firfilt_##K q, float fc, yagi_cf32 *H) {       \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_freqresponse(yagi_hip_firfilt_##K q, float fc, yagi_cf32 *H) try {   \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(H);                                                                               \
         *H = cx_mul(taps_freqresponse(q->h, fc), cx_val(q->scale));                                 \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firfilt_##K##_groupdelay(yagi_hip_firfilt_##K q, float fc, float *delay) {         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_groupdelay(yagi_hip_firfilt_##K q, float fc, float *delay) try {     \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(delay);                                                                           \
         return taps_groupdelay(q->h, fc, delay);                                                    \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
                                                                                                     \
     int yagi_hip_firdecim_##K##_create(size_t M, const C *h, size_t h_len,                          \
-                                       yagi_hip_firdecim_##K *q) {                                  \
+                                       yagi_hip_firdecim_##K *q) try {                              \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -990,9 +990,9 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->init(M, h, h_len));                                                               \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firdecim_##K##_create_kaiser(size_t M, size_t m, float as_,                        \
-                                              yagi_hip_firdecim_##K *q) {                           \
+                                              yagi_hip_firdecim_##K *q) try {                       \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (M < 2) return fail(YAGI_ERR_CONFIG, "decim factor must be greater than 1");             \
@@ -1003,12 +1003,12 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         std::vector<C> hc(hf.size());                                                               \
         for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firdecim_##K##_create(M, hc.data(), hc.size(), q);                          \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_destroy(yagi_hip_firdecim_##K q) {                                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_destroy(yagi_hip_firdecim_##K q) try {                              \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_clone(yagi_hip_firdecim_##K q, yagi_hip_firdecim_##K *out) {        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_clone(yagi_hip_firdecim_##K q, yagi_hip_firdecim_##K *out) try {    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -1020,61 +1020,61 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_set_stream(yagi_hip_firdecim_##K q, yagi_stream_t s) {              \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_set_stream(yagi_hip_firdecim_##K q, yagi_stream_t s) try {          \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_reset(yagi_hip_firdecim_##K q) {                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_reset(yagi_hip_firdecim_##K q) try {                                \
         CHECK_Q(q);                                                                                 \
         return q->w.reset(q->st);                                                                   \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_get_decim_rate(yagi_hip_firdecim_##K q, size_t *M) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_get_decim_rate(yagi_hip_firdecim_##K q, size_t *M) try {            \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(M);                                                                               \
         *M = (size_t)q->M;                                                                          \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_set_scale(yagi_hip_firdecim_##K q, C s) {                           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_set_scale(yagi_hip_firdecim_##K q, C s) try {                       \
         CHECK_Q(q);                                                                                 \
         q->scale = s;                                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_get_scale(yagi_hip_firdecim_##K q, C *s) {                          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_get_scale(yagi_hip_firdecim_##K q, C *s) try {                      \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(s);                                                                               \
         *s = q->scale;                                                                              \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_freqresp(yagi_hip_firdecim_##K q, float fc, yagi_cf32 *H) {         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_freqresp(yagi_hip_firdecim_##K q, float fc, yagi_cf32 *H) try {     \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(H);                                                                               \
         *H = cx_mul(taps_freqresponse(q->h, fc), cx_val(q->scale));                                 \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y) {     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y) try { \
         CHECK_Q(q);                                                                                 \
         return firdecim_block_host<KT>(q, x, nx, 1, y);                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firdecim_##K##_execute_block(yagi_hip_firdecim_##K q, const T *x, size_t nx,       \
-                                              size_t n, T *y) {                                     \
+                                              size_t n, T *y) try {                                 \
         CHECK_Q(q);                                                                                 \
         return firdecim_block_host<KT>(q, x, nx, n, y);                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firdecim_##K##_execute_block_dev(yagi_hip_firdecim_##K q, const T *x, size_t n,    \
-                                                  T *y) {                                           \
+                                                  T *y) try {                                       \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n * (size_t)q->M, y, n);                                                   \
         return q->block_dev(x, n, y);                                                               \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
                                                                                                     \
-    int yagi_hip_firpfb_##K##_create(size_t nf, const C *h, size_t h_len, yagi_hip_firpfb_##K *q) { \
+    int yagi_hip_firpfb_##K##_create(size_t nf, const C *h, size_t h_len, yagi_hip_firpfb_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -1082,9 +1082,9 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->init(nf, h, h_len));                                                              \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_create_kaiser(size_t nf, size_t m, float fc, float as_,               \
-                                            yagi_hip_firpfb_##K *q) {                               \
+                                            yagi_hip_firpfb_##K *q) try {                           \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (nf == 0) return fail(YAGI_ERR_CONFIG, "number of filters must be greater than zero");   \
@@ -1097,15 +1097,15 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         std::vector<C> hc(hf.size());                                                               \
         for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firpfb_##K##_create(nf, hc.data(), hc.size(), q);                           \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_create_default(size_t nf, size_t m, yagi_hip_firpfb_##K *q) {         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_create_default(size_t nf, size_t m, yagi_hip_firpfb_##K *q) try {     \
         return yagi_hip_firpfb_##K##_create_kaiser(nf, m, 0.5f, 60.0f, q);                          \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_destroy(yagi_hip_firpfb_##K q) {                                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_destroy(yagi_hip_firpfb_##K q) try {                                  \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_clone(yagi_hip_firpfb_##K q, yagi_hip_firpfb_##K *out) {              \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_clone(yagi_hip_firpfb_##K q, yagi_hip_firpfb_##K *out) try {          \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -1121,63 +1121,63 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY(o->w.clone_from(q->w, q->st));                                                       \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_set_stream(yagi_hip_firpfb_##K q, yagi_stream_t s) {                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_set_stream(yagi_hip_firpfb_##K q, yagi_stream_t s) try {              \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_reset(yagi_hip_firpfb_##K q) {                                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_reset(yagi_hip_firpfb_##K q) try {                                    \
         CHECK_Q(q);                                                                                 \
         return q->w.reset(q->st);                                                                   \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_set_scale(yagi_hip_firpfb_##K q, C s) {                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_set_scale(yagi_hip_firpfb_##K q, C s) try {                           \
         CHECK_Q(q);                                                                                 \
         q->scale = s;                                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_get_scale(yagi_hip_firpfb_##K q, C *s) {                              \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_get_scale(yagi_hip_firpfb_##K q, C *s) try {                          \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(s);                                                                               \
         *s = q->scale;                                                                              \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_push(yagi_hip_firpfb_##K q, T x) {                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_push(yagi_hip_firpfb_##K q, T x) try {                                \
         CHECK_Q(q);                                                                                 \
         q->w.push(x);                                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_write(yagi_hip_firpfb_##K q, const T *x, size_t n) {                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_write(yagi_hip_firpfb_##K q, const T *x, size_t n) try {              \
         CHECK_Q(q);                                                                                 \
         if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
         for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_execute(yagi_hip_firpfb_##K q, size_t i, T *y) {                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_execute(yagi_hip_firpfb_##K q, size_t i, T *y) try {                  \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(y);                                                                               \
         YG_TRY(q->check_branch(i));                                                                 \
         YG_TRY(q->w.flush(q->st));                                                                  \
         return window_dot<KT>(q->w.dev(), q->taps.as<C>() + i * (size_t)q->Ls, q->Ls, q->scale,     \
                               q->ws, y, q->st);                                                     \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_execute_block(yagi_hip_firpfb_##K q, size_t i, const T *x, size_t nx, \
-                                            T *y, size_t ny) {                                      \
+                                            T *y, size_t ny) try {                                  \
         CHECK_Q(q);                                                                                 \
         return firpfb_block_host<KT>(q, i, x, nx, y, ny);                                           \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_execute_block_dev(yagi_hip_firpfb_##K q, size_t i, const T *x,        \
-                                                size_t n, T *y) {                                   \
+                                                size_t n, T *y) try {                               \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return q->check_branch(i);                                                      \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n, y, n);                                                                  \
         return q->block_dev(i, x, n, y);                                                            \
-    }                                                                                               \
-    int yagi_hip_firpfb_##K##_execute_all_dev(yagi_hip_firpfb_##K q, const T *x, size_t n, T *y) {  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firpfb_##K##_execute_all_dev(yagi_hip_firpfb_##K q, const T *x, size_t n, T *y) try { \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
@@ -1187,9 +1187,9 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY((launch_firpfb_all<KT>(q->w.dev(), x, q->taps.as<C>(), q->nf, q->Ls, q->scale, y, n, \
                                       q->st)));                                                     \
         return q->w.advance(x, n, q->st);                                                           \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_execute_select_dev(yagi_hip_firpfb_##K q, const uint32_t *idx,        \
-                                                 const T *x, size_t n, T *y) {                      \
+                                                 const T *x, size_t n, T *y) try {                  \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(idx);                                                                             \
@@ -1200,7 +1200,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         YG_TRY((launch_firpfb_select<KT>(q->w.dev(), x, q->taps.as<C>(), idx, q->nf, q->Ls,         \
                                          q->scale, y, n, q->st)));                                  \
         return q->w.advance(x, n, q->st);                                                           \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_FIR_IMPL(rrrf, RRRF, float, float)
@@ -1227,34 +1227,34 @@ struct yagi_hip_fft_s : FftPlan {};
 
 extern "C" {
 
-int yagi_hip_fft_create(size_t n, int direction, yagi_hip_fft *plan) {
+int yagi_hip_fft_create(size_t n, int direction, yagi_hip_fft *plan) try {
     CHECK_PTR(plan);
     *plan = nullptr;
     auto p = std::make_unique<yagi_hip_fft_s>();
     YG_TRY(fft_plan_init(*p, n, direction));
     *plan = p.release();
     return YAGI_OK;
-}
-int yagi_hip_fft_destroy(yagi_hip_fft plan) { delete plan; return YAGI_OK; }
-int yagi_hip_fft_clone(yagi_hip_fft plan, yagi_hip_fft *out) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_destroy(yagi_hip_fft plan) try { delete plan; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_clone(yagi_hip_fft plan, yagi_hip_fft *out) try {
     CHECK_Q(plan);
     return yagi_hip_fft_create((size_t)plan->d.n, plan->d.dir, out);
-}
-int yagi_hip_fft_len(yagi_hip_fft plan, size_t *n) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_len(yagi_hip_fft plan, size_t *n) try {
     CHECK_Q(plan);
     CHECK_PTR(n);
     *n = (size_t)plan->d.n;
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_fft_run_batch_dev(yagi_hip_fft plan, const yagi_cf32 *in, yagi_cf32 *out, size_t batch,
-                               yagi_stream_t s) {
+                               yagi_stream_t s) try {
     CHECK_Q(plan);
     if (batch == 0) return YAGI_OK;
     CHECK_PTR(in);
     CHECK_PTR(out);
     return launch_fft_batch(plan->d, in, out, batch, to_stream(s));
-}
-int yagi_hip_fft_run(yagi_hip_fft plan, const yagi_cf32 *input, size_t n_in, yagi_cf32 *output, size_t n_out) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_run(yagi_hip_fft plan, const yagi_cf32 *input, size_t n_in, yagi_cf32 *output, size_t n_out) try {
     CHECK_Q(plan);
     const size_t n = (size_t)plan->d.n;
     // the reference panics on a length mismatch (copy_from_slice, fft/mod.rs:46)
@@ -1266,14 +1266,14 @@ int yagi_hip_fft_run(yagi_hip_fft plan, const yagi_cf32 *input, size_t n_in, yag
     YG_TRY(upload(plan->ws.x.p, input, n * sizeof(cf32), nullptr));
     YG_TRY(launch_fft_batch(plan->d, plan->ws.x.as<cf32>(), plan->ws.y.as<cf32>(), 1, nullptr));
     return download(output, plan->ws.y.p, n * sizeof(cf32), nullptr);
-}
-int yagi_hip_fft_shift_dev(yagi_cf32 *buf, size_t n, size_t batch, yagi_stream_t s) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_shift_dev(yagi_cf32 *buf, size_t n, size_t batch, yagi_stream_t s) try {
     if (n == 0 || batch == 0) return YAGI_OK;
     CHECK_PTR(buf);
     YG_TRY(require_device());
     return launch_fft_shift(buf, n, batch, to_stream(s));
-}
-int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n) try {
     if (n < 2) return YAGI_OK;
     CHECK_PTR(buf);
     YG_TRY(require_device());
@@ -1282,14 +1282,14 @@ int yagi_hip_fft_shift(yagi_cf32 *buf, size_t n) {
     YG_TRY(upload(d.p, buf, n * sizeof(cf32), nullptr));
     YG_TRY(launch_fft_shift(d.as<cf32>(), n, 1, nullptr));
     return download(buf, d.p, n * sizeof(cf32), nullptr);
-}
-int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n, int direction) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_fft_run_oneshot(const yagi_cf32 *input, yagi_cf32 *output, size_t n, int direction) try {
     yagi_hip_fft p = nullptr;
     YG_TRY(yagi_hip_fft_create(n, direction, &p));
     int rc = yagi_hip_fft_run(p, input, n, output, n);
     yagi_hip_fft_destroy(p);
     return rc;
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 }  // extern "C"
 
@@ -1340,7 +1340,7 @@ struct FirInterp {
     struct yagi_hip_firinterp_##K##_s : FirInterp<KT> {};                                           \
     extern "C" {                                                                                    \
     int yagi_hip_firinterp_##K##_create(size_t interp, const C *h, size_t h_len,                    \
-                                        yagi_hip_firinterp_##K *q) {                                \
+                                        yagi_hip_firinterp_##K *q) try {                            \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -1348,9 +1348,9 @@ struct FirInterp {
         YG_TRY(o->init(interp, h, h_len));                                                          \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firinterp_##K##_create_kaiser(size_t interp, size_t m, float as_,                  \
-                                               yagi_hip_firinterp_##K *q) {                         \
+                                               yagi_hip_firinterp_##K *q) try {                     \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (interp < 2) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
@@ -1361,8 +1361,8 @@ struct FirInterp {
         std::vector<C> hc(hf.size());                                                               \
         for (size_t i = 0; i < hf.size(); ++i) hc[i] = to_c(hf[i], (C *)nullptr);                   \
         return yagi_hip_firinterp_##K##_create(interp, hc.data(), hc.size() - 1, q);                \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_create_linear(size_t interp, yagi_hip_firinterp_##K *q) {          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_create_linear(size_t interp, yagi_hip_firinterp_##K *q) try {      \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (interp < 1) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
@@ -1372,8 +1372,8 @@ struct FirInterp {
             hc[interp + i] = to_c(1.0f - (float)i / (float)interp, (C *)nullptr);                   \
         }                                                                                           \
         return yagi_hip_firinterp_##K##_create(interp, hc.data(), hc.size(), q);                    \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_create_window(size_t interp, size_t m, yagi_hip_firinterp_##K *q) {\
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_create_window(size_t interp, size_t m, yagi_hip_firinterp_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (interp < 1) return fail(YAGI_ERR_CONFIG, "interp factor must be greater than 1");       \
@@ -1385,12 +1385,12 @@ struct FirInterp {
             hc[i] = to_c(sv * sv, (C *)nullptr);                                                    \
         }                                                                                           \
         return yagi_hip_firinterp_##K##_create(interp, hc.data(), hl, q);                           \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_destroy(yagi_hip_firinterp_##K q) {                                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_destroy(yagi_hip_firinterp_##K q) try {                            \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_clone(yagi_hip_firinterp_##K q, yagi_hip_firinterp_##K *out) {     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_clone(yagi_hip_firinterp_##K q, yagi_hip_firinterp_##K *out) try { \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -1408,49 +1408,49 @@ struct FirInterp {
         YG_TRY(o->bank.w.clone_from(q->bank.w, q->bank.st));                                        \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_set_stream(yagi_hip_firinterp_##K q, yagi_stream_t s) {            \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_set_stream(yagi_hip_firinterp_##K q, yagi_stream_t s) try {        \
         CHECK_Q(q);                                                                                 \
         if (q->bank.st == to_stream(s)) return YAGI_OK;                                             \
         YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
         q->bank.st = to_stream(s);                                                                  \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_reset(yagi_hip_firinterp_##K q) {                                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_reset(yagi_hip_firinterp_##K q) try {                              \
         CHECK_Q(q);                                                                                 \
         return q->bank.w.reset(q->bank.st);                                                         \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_get_interp_rate(yagi_hip_firinterp_##K q, size_t *interp) {        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_get_interp_rate(yagi_hip_firinterp_##K q, size_t *interp) try {    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(interp);                                                                          \
         *interp = (size_t)q->interp;                                                                \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_get_sub_len(yagi_hip_firinterp_##K q, size_t *hs) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_get_sub_len(yagi_hip_firinterp_##K q, size_t *hs) try {            \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(hs);                                                                              \
         *hs = (size_t)q->hs;                                                                        \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_set_scale(yagi_hip_firinterp_##K q, C scale) {                     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_set_scale(yagi_hip_firinterp_##K q, C scale) try {                 \
         CHECK_Q(q);                                                                                 \
         q->bank.scale = scale;                                                                      \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_get_scale(yagi_hip_firinterp_##K q, C *scale) {                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_get_scale(yagi_hip_firinterp_##K q, C *scale) try {                \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(scale);                                                                           \
         *scale = q->bank.scale;                                                                     \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_execute(yagi_hip_firinterp_##K q, T x, T *y, size_t ny) {          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_execute(yagi_hip_firinterp_##K q, T x, T *y, size_t ny) try {      \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(y);                                                                               \
         if (ny < (size_t)q->interp) return fail(YAGI_ERR_CONFIG, "output must hold interp samples");\
         return q->block_host(&x, 1, y);                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firinterp_##K##_execute_block(yagi_hip_firinterp_##K q, const T *x, size_t nx,     \
-                                               T *y, size_t ny) {                                   \
+                                               T *y, size_t ny) try {                               \
         CHECK_Q(q);                                                                                 \
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
@@ -1458,20 +1458,20 @@ struct FirInterp {
         if (ny < nx * (size_t)q->interp)                                                            \
             return fail(YAGI_ERR_CONFIG, "output must hold n*interp samples");                      \
         return q->block_host(x, nx, y);                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firinterp_##K##_execute_block_dev(yagi_hip_firinterp_##K q, const T *x, size_t n,  \
-                                                   T *y) {                                          \
+                                                   T *y) try {                                      \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n, y, n * (size_t)q->bank.nf);                                             \
         return q->block_dev(x, n, y);                                                               \
-    }                                                                                               \
-    int yagi_hip_firinterp_##K##_flush(yagi_hip_firinterp_##K q, T *y, size_t ny) {                 \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firinterp_##K##_flush(yagi_hip_firinterp_##K q, T *y, size_t ny) try {             \
         T zero{};                                                                                   \
         return yagi_hip_firinterp_##K##_execute(q, zero, y, ny);                                    \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_FIRINTERP_IMPL(rrrf, RRRF, float, float)
@@ -1530,7 +1530,7 @@ struct RresampObj {
     struct yagi_hip_rresamp_##K##_s : RresampObj<KT> {};                                            \
     extern "C" {                                                                                    \
     int yagi_hip_rresamp_##K##_create(size_t interp, size_t decim, size_t m, const C *h,            \
-                                      size_t h_len, yagi_hip_rresamp_##K *q) {                      \
+                                      size_t h_len, yagi_hip_rresamp_##K *q) try {                  \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -1538,9 +1538,9 @@ struct RresampObj {
         YG_TRY(o->init(interp, decim, m, h, h_len));                                                \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_rresamp_##K##_create_kaiser(size_t interp, size_t decim, size_t m, float bw,       \
-                                             float as_, yagi_hip_rresamp_##K *q) {                  \
+                                             float as_, yagi_hip_rresamp_##K *q) try {              \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (interp == 0 || decim == 0) return fail(YAGI_ERR_CONFIG, "gcd: arguments must be greater than zero"); \
@@ -1558,15 +1558,15 @@ struct RresampObj {
         (*q)->bank.scale = to_c(2.0f * bw * std::sqrt((float)decim / (float)interp), (C *)nullptr); \
         (*q)->block_len = (int)g;                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_create_default(size_t interp, size_t decim, yagi_hip_rresamp_##K *q) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_create_default(size_t interp, size_t decim, yagi_hip_rresamp_##K *q) try { \
         return yagi_hip_rresamp_##K##_create_kaiser(interp, decim, 12, 0.5f, 60.0f, q);  /* :99-104 */ \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_destroy(yagi_hip_rresamp_##K q) {                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_destroy(yagi_hip_rresamp_##K q) try {                                \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_clone(yagi_hip_rresamp_##K q, yagi_hip_rresamp_##K *out) {  /* derive(Clone) rresamp.rs:8 */ \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_clone(yagi_hip_rresamp_##K q, yagi_hip_rresamp_##K *out) try {  /* derive(Clone) rresamp.rs:8 */ \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -1583,47 +1583,47 @@ struct RresampObj {
         o->P = q->P; o->Q = q->Q; o->m = q->m; o->block_len = q->block_len;                         \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_set_stream(yagi_hip_rresamp_##K q, yagi_stream_t s) try {            \
         CHECK_Q(q);                                                                                 \
         if (q->bank.st == to_stream(s)) return YAGI_OK;                                             \
         YG_HIP(hipStreamSynchronize(q->bank.st));                                                   \
         q->bank.st = to_stream(s);                                                                  \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_reset(yagi_hip_rresamp_##K q) {                                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_reset(yagi_hip_rresamp_##K q) try {                                  \
         CHECK_Q(q);                                                                                 \
         return q->bank.w.reset(q->bank.st);                                                         \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_set_scale(yagi_hip_rresamp_##K q, C scale) {                         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_set_scale(yagi_hip_rresamp_##K q, C scale) try {                     \
         CHECK_Q(q);                                                                                 \
         q->bank.scale = scale;                                                                      \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_get_scale(yagi_hip_rresamp_##K q, C *scale) {                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_get_scale(yagi_hip_rresamp_##K q, C *scale) try {                    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(scale);                                                                           \
         *scale = q->bank.scale;                                                                     \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_rresamp_##K##_get_params(yagi_hip_rresamp_##K q, size_t *interp, size_t *decim,    \
-                                          size_t *m, size_t *block_len) {                           \
+                                          size_t *m, size_t *block_len) try {                       \
         CHECK_Q(q);                                                                                 \
         if (interp) *interp = (size_t)q->P;                                                         \
         if (decim) *decim = (size_t)q->Q;                                                           \
         if (m) *m = (size_t)q->m;                                                                   \
         if (block_len) *block_len = (size_t)q->block_len;                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_rresamp_##K##_write(yagi_hip_rresamp_##K q, const T *x, size_t n) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_rresamp_##K##_write(yagi_hip_rresamp_##K q, const T *x, size_t n) try {            \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         for (size_t i = 0; i < n; ++i) q->bank.w.push(x[i]);                                        \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_rresamp_##K##_execute(yagi_hip_rresamp_##K q, const T *x, size_t nx, T *y,         \
-                                       size_t ny) {                                                 \
+                                       size_t ny) try {                                             \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
@@ -1631,9 +1631,9 @@ struct RresampObj {
         if (nx < bl * (size_t)q->Q) return fail(YAGI_ERR_RANGE, "input must hold Q*block_len samples"); \
         if (ny < bl * (size_t)q->P) return fail(YAGI_ERR_RANGE, "output must hold P*block_len samples"); \
         return q->blocks_host(x, bl, y);                                                            \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_rresamp_##K##_execute_block(yagi_hip_rresamp_##K q, const T *x, size_t nx,         \
-                                             size_t n, T *y, size_t ny) {                           \
+                                             size_t n, T *y, size_t ny) try {                       \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
@@ -1642,16 +1642,16 @@ struct RresampObj {
         if (nx < nb * (size_t)q->Q) return fail(YAGI_ERR_RANGE, "input must hold n*Q*block_len samples"); \
         if (ny < nb * (size_t)q->P) return fail(YAGI_ERR_RANGE, "output must hold n*P*block_len samples"); \
         return q->blocks_host(x, nb, y);                                                            \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_rresamp_##K##_execute_block_dev(yagi_hip_rresamp_##K q, const T *x, size_t n,      \
-                                                 T *y) {                                            \
+                                                 T *y) try {                                        \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n * (size_t)q->block_len * (size_t)q->Q, y, n * (size_t)q->block_len * (size_t)q->P); \
         return q->blocks_dev(x, n * (size_t)q->block_len, y);                                       \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_RRESAMP_IMPL(rrrf, RRRF, float, float)
@@ -1804,76 +1804,76 @@ struct SpgramObj {
     struct yagi_hip_spgram##K##_s : SpgramObj<T> {};                                                \
     extern "C" {                                                                                    \
     int yagi_hip_spgram##K##_create(size_t nfft, int wtype, size_t window_len, size_t delay,        \
-                                    yagi_hip_spgram##K *q) {                                        \
+                                    yagi_hip_spgram##K *q) try {                                    \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         auto o = std::make_unique<yagi_hip_spgram##K##_s>();                                        \
         YG_TRY(o->init(nfft, wtype, window_len, delay));                                            \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_create_default(size_t nfft, yagi_hip_spgram##K *q) {                   \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_create_default(size_t nfft, yagi_hip_spgram##K *q) try {               \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (nfft < 2) return fail(YAGI_ERR_CONFIG, "fft size must be at least 2");                  \
         return yagi_hip_spgram##K##_create(nfft, YAGI_WINDOW_KAISER, nfft / 2, nfft / 4, q);        \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_destroy(yagi_hip_spgram##K q) {                                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_destroy(yagi_hip_spgram##K q) try {                                    \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_set_stream(yagi_hip_spgram##K q, yagi_stream_t s) {                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_set_stream(yagi_hip_spgram##K q, yagi_stream_t s) try {                \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_clear(yagi_hip_spgram##K q) {                                          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_clear(yagi_hip_spgram##K q) try {                                      \
         CHECK_Q(q);                                                                                 \
         YG_TRY(q->flush());                                                                         \
         return q->clear();                                                                          \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_reset(yagi_hip_spgram##K q) {                                          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_reset(yagi_hip_spgram##K q) try {                                      \
         CHECK_Q(q);                                                                                 \
         return q->reset();                                                                          \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_set_alpha(yagi_hip_spgram##K q, float alpha) {                         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_set_alpha(yagi_hip_spgram##K q, float alpha) try {                     \
         CHECK_Q(q);                                                                                 \
         if (alpha != -1.0f && (alpha < 0.0f || alpha > 1.0f))                                       \
             return fail(YAGI_ERR_CONFIG, "alpha must be in {-1,[0,1]}");                            \
         YG_TRY(q->flush());                                                                         \
         q->set_alpha_unchecked(alpha);                                                              \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_get_alpha(yagi_hip_spgram##K q, float *alpha) {                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_get_alpha(yagi_hip_spgram##K q, float *alpha) try {                    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(alpha);                                                                           \
         *alpha = q->alpha;                                                                          \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_set_freq(yagi_hip_spgram##K q, float freq) {                           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_set_freq(yagi_hip_spgram##K q, float freq) try {                       \
         CHECK_Q(q);                                                                                 \
         q->frequency = freq;                                                                        \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_set_rate(yagi_hip_spgram##K q, float rate) {                           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_set_rate(yagi_hip_spgram##K q, float rate) try {                       \
         CHECK_Q(q);                                                                                 \
         if (rate <= 0.0f) return fail(YAGI_ERR_CONFIG, "sample rate must be greater than zero");    \
         q->sample_rate = rate;                                                                      \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_spgram##K##_get_params(yagi_hip_spgram##K q, size_t *nfft, size_t *window_len,     \
-                                        size_t *delay, int *wtype) {                                \
+                                        size_t *delay, int *wtype) try {                            \
         CHECK_Q(q);                                                                                 \
         if (nfft) *nfft = (size_t)q->nfft;                                                          \
         if (window_len) *window_len = (size_t)q->wlen;                                              \
         if (delay) *delay = (size_t)q->delay;                                                       \
         if (wtype) *wtype = q->wtype;                                                               \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_spgram##K##_get_counters(yagi_hip_spgram##K q, uint64_t *ns, uint64_t *nst,        \
-                                          uint64_t *nt, uint64_t *ntt) {                            \
+                                          uint64_t *nt, uint64_t *ntt) try {                        \
         CHECK_Q(q);                                                                                 \
         YG_TRY(q->flush());                                                                         \
         if (ns) *ns = q->num_samples;                                                               \
@@ -1881,38 +1881,38 @@ struct SpgramObj {
         if (nt) *nt = q->num_transforms;                                                            \
         if (ntt) *ntt = q->num_transforms_total;                                                    \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_push(yagi_hip_spgram##K q, T x) {                                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_push(yagi_hip_spgram##K q, T x) try {                                  \
         CHECK_Q(q);                                                                                 \
         q->queue.push_back(x);                                                                      \
         if (q->queue.size() >= (size_t)1 << 20) return q->flush();                                  \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_write(yagi_hip_spgram##K q, const T *x, size_t n) {                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_write(yagi_hip_spgram##K q, const T *x, size_t n) try {                \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         YG_TRY(q->flush());                                                                         \
         return q->write_host(x, n);                                                                 \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_write_dev(yagi_hip_spgram##K q, const T *x, size_t n) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_write_dev(yagi_hip_spgram##K q, const T *x, size_t n) try {            \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         YG_TRY(q->flush());                                                                         \
         return q->write_dev(x, n);                                                                  \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_get_psd_mag(yagi_hip_spgram##K q, float *psd, size_t n) {              \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_get_psd_mag(yagi_hip_spgram##K q, float *psd, size_t n) try {          \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(psd);                                                                             \
         return q->get(psd, n, false);                                                               \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_get_psd(yagi_hip_spgram##K q, float *psd, size_t n) {                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_get_psd(yagi_hip_spgram##K q, float *psd, size_t n) try {              \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(psd);                                                                             \
         return q->get(psd, n, true);                                                                \
-    }                                                                                               \
-    int yagi_hip_spgram##K##_estimate_psd(size_t nfft, const T *x, size_t n, float *psd) {          \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_spgram##K##_estimate_psd(size_t nfft, const T *x, size_t n, float *psd) try {      \
         CHECK_PTR(psd);                                                                             \
         if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
         yagi_hip_spgram##K q = nullptr;                                                             \
@@ -1921,7 +1921,7 @@ struct SpgramObj {
         YG_TRY(q->write_host(x, n));                                                                \
         if (q->num_transforms == 0) YG_TRY(q->run_frames(nullptr, -1, 1));   /* q.step() :325-327 */ \
         return q->get(psd, nfft, true);                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_SPGRAM_IMPL(cf, yagi_cf32)
@@ -2027,7 +2027,7 @@ struct FftFiltObj {
 #define YAGI_FFTFILT_IMPL(K, KT, T, C)                                                              \
     struct yagi_hip_fftfilt_##K##_s : FftFiltObj<KT> {};                                            \
     extern "C" {                                                                                    \
-    int yagi_hip_fftfilt_##K##_create(const C *h, size_t h_len, size_t n, yagi_hip_fftfilt_##K *q) {\
+    int yagi_hip_fftfilt_##K##_create(const C *h, size_t h_len, size_t n, yagi_hip_fftfilt_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                     \
@@ -2035,12 +2035,12 @@ struct FftFiltObj {
         YG_TRY(o->init(h, h_len, n));                                                               \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_destroy(yagi_hip_fftfilt_##K q) {                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_destroy(yagi_hip_fftfilt_##K q) try {                                \
         delete q;                                                                                   \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_clone(yagi_hip_fftfilt_##K q, yagi_hip_fftfilt_##K *out) {           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_clone(yagi_hip_fftfilt_##K q, yagi_hip_fftfilt_##K *out) try {       \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -2058,61 +2058,61 @@ struct FftFiltObj {
         }                                                                                           \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_set_stream(yagi_hip_fftfilt_##K q, yagi_stream_t s) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_set_stream(yagi_hip_fftfilt_##K q, yagi_stream_t s) try {            \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_reset(yagi_hip_fftfilt_##K q) {                                      \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_reset(yagi_hip_fftfilt_##K q) try {                                  \
         CHECK_Q(q);                                                                                 \
         return q->reset();                                                                          \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_set_scale(yagi_hip_fftfilt_##K q, C scale) {                         \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_set_scale(yagi_hip_fftfilt_##K q, C scale) try {                     \
         CHECK_Q(q);                                                                                 \
         q->scale = div_scalar(scale, 2.0f * (float)q->n);                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_get_scale(yagi_hip_fftfilt_##K q, C *scale) {                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_get_scale(yagi_hip_fftfilt_##K q, C *scale) try {                    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(scale);                                                                           \
         *scale = mul_scalar(q->scale, 2.0f * (float)q->n);                                          \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_fftfilt_##K##_get_length(yagi_hip_fftfilt_##K q, size_t *h_len) {                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_fftfilt_##K##_get_length(yagi_hip_fftfilt_##K q, size_t *h_len) try {              \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(h_len);                                                                           \
         *h_len = q->h.size();                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_fftfilt_##K##_execute(yagi_hip_fftfilt_##K q, const T *x, size_t nx, T *y,         \
-                                       size_t ny) {                                                 \
+                                       size_t ny) try {                                             \
         CHECK_Q(q);                                                                                 \
         if (nx != (size_t)q->n || ny != (size_t)q->n)                                               \
             return fail(YAGI_ERR_CONFIG, "input and output lengths must match filter block size");  \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->blocks_host(x, 1, y);                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_fftfilt_##K##_execute_blocks(yagi_hip_fftfilt_##K q, const T *x, size_t nblocks,   \
-                                              T *y) {                                               \
+                                              T *y) try {                                           \
         CHECK_Q(q);                                                                                 \
         if (nblocks == 0) return YAGI_OK;                                                           \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->blocks_host(x, nblocks, y);                                                       \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_fftfilt_##K##_execute_blocks_dev(yagi_hip_fftfilt_##K q, const T *x,               \
-                                                  size_t nblocks, T *y) {                           \
+                                                  size_t nblocks, T *y) try {                       \
         CHECK_Q(q);                                                                                 \
         if (nblocks == 0) return YAGI_OK;                                                           \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, nblocks * (size_t)q->n, y, nblocks * (size_t)q->n);                        \
         return q->blocks_dev(x, nblocks, y);                                                        \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_FFTFILT_IMPL(rrrf, RRRF, float, float)
@@ -2124,7 +2124,7 @@ struct yagi_hip_firfft_crcf_s : FirFft {};
 
 extern "C" {
 
-int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_hip_firfft_crcf *q) {
+int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_hip_firfft_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (h_len && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");
@@ -2137,18 +2137,18 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
     else YG_TRY(fft_plan_init(o->plan, nfft, YAGI_FFT_FORWARD));      // any size the Fft object supports
     *q = o.release();
     return YAGI_OK;
-}
-int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) { delete q; return YAGI_OK; }
-int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s) try {
     CHECK_Q(q);
     if (q->fir.st == to_stream(s)) return YAGI_OK;
     YG_HIP(hipStreamSynchronize(q->fir.st));
     q->fir.st = to_stream(s);
     return YAGI_OK;
-}
-int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) { CHECK_Q(q); q->fir.scale = scale; return YAGI_OK; }
-int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) { CHECK_Q(q); return q->fir.w.reset(q->fir.st); }
-int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) try { CHECK_Q(q); q->fir.scale = scale; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) try { CHECK_Q(q); return q->fir.w.reset(q->fir.st); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) try {
     CHECK_Q(q);
     if (variant < 0 || variant > 4) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
     if (q->nfft != 4096 && variant != 0 && variant != 3)
@@ -2159,8 +2159,8 @@ int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) {
     if (variant == 1 && q->fir.Lp > kSlideMaxTaps) return fail(YAGI_ERR_CONFIG, "sliding variant needs <= %d taps", kSlideMaxTaps);
     q->variant = variant;
     return YAGI_OK;
-}
-int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2216,8 +2216,8 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     YG_TRY(launch_firfft_crcf_4096(f.w.dev(), x, f.taps_pad.as<float>(), f.apack.as<float>(), f.L, f.Lp, f.Lm, f.scale,
                                    q->tw.as<cf32>(), spectra, nframes, q->variant, f.st));
     return f.w.advance(x, nframes * q->nfft, f.st);
-}
-int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *spectra) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2228,7 +2228,7 @@ int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, siz
     YG_TRY(upload(q->xin.p, x, bytes, q->fir.st));
     YG_TRY(yagi_hip_firfft_crcf_execute_dev(q, q->xin.as<cf32>(), nframes, q->yout.as<cf32>()));
     return download(spectra, q->yout.p, bytes, q->fir.st);
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 }  // extern "C"
 
@@ -2238,7 +2238,7 @@ struct yagi_hip_firpfbch2_crcf_s : PfbCh2 {};
 
 extern "C" {
 
-int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_firpfbch_crcf *q) {
+int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_firpfbch_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (M == 0) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than zero");
@@ -2257,8 +2257,8 @@ int yagi_hip_firpfbch_crcf_create(size_t M, size_t p, const float *h, yagi_hip_f
     YG_TRY(o->syn_hist.init((int)(hl ? hl : 1), nullptr));
     *q = o.release();
     return YAGI_OK;
-}
-int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch_crcf *q) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (M == 0) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than zero");
@@ -2266,21 +2266,21 @@ int yagi_hip_firpfbch_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip
     std::vector<float> hf;
     YG_TRY(design_kaiser(2 * M * m + 1, 0.5f / (float)M, std::fabs(as_), 0.0f, hf));
     return yagi_hip_firpfbch_crcf_create(M, 2 * m, hf.data(), q);
-}
-int yagi_hip_firpfbch_crcf_destroy(yagi_hip_firpfbch_crcf q) { delete q; return YAGI_OK; }
-int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_destroy(yagi_hip_firpfbch_crcf q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_set_stream(yagi_hip_firpfbch_crcf q, yagi_stream_t s) try {
     CHECK_Q(q);
     if (q->st == to_stream(s)) return YAGI_OK;      // unchanged: no host synchronisation
     YG_HIP(hipStreamSynchronize(q->st));
     q->st = to_stream(s);
     return YAGI_OK;
-}
-int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_reset(yagi_hip_firpfbch_crcf q) try {
     CHECK_Q(q);
     YG_TRY(q->hist.reset(q->st));
     return q->syn_hist.reset(q->st);
-}
-int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2293,8 +2293,8 @@ int yagi_hip_firpfbch_crcf_analyzer_execute_dev(yagi_hip_firpfbch_crcf q, const 
     if (written) { q->hist.flip(); return YAGI_OK; }         // the kernel's last workgroup wrote the next history
     if (q->p > 1) return q->hist.advance(x, nframes * (size_t)q->M, q->st);
     return YAGI_OK;
-}
-int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2305,9 +2305,9 @@ int yagi_hip_firpfbch_crcf_analyzer_execute(yagi_hip_firpfbch_crcf q, const yagi
     YG_TRY(upload(q->ws.x.p, x, bytes, q->st));
     YG_TRY(yagi_hip_firpfbch_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nframes, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, bytes, q->st);
-}
+} catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2316,8 +2316,8 @@ int yagi_hip_firpfbch_crcf_synthesizer_execute_dev(yagi_hip_firpfbch_crcf q, con
     YG_TRY(launch_firpfbch_syn(q->syn_hist.dev(), x, q->h.as<float>(), q->M, q->p, q->tw.as<cf32>(), y, nframes, q->st));
     if (q->p > 1) return q->syn_hist.advance(x, nframes * (size_t)q->M, q->st);
     return YAGI_OK;
-}
-int yagi_hip_firpfbch_crcf_synthesizer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch_crcf_synthesizer_execute(yagi_hip_firpfbch_crcf q, const yagi_cf32 *x, size_t nframes, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nframes == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2328,9 +2328,9 @@ int yagi_hip_firpfbch_crcf_synthesizer_execute(yagi_hip_firpfbch_crcf q, const y
     YG_TRY(upload(q->ws.x.p, x, bytes, q->st));
     YG_TRY(yagi_hip_firpfbch_crcf_synthesizer_execute_dev(q, q->ws.x.as<cf32>(), nframes, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, bytes, q->st);
-}
+} catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q) {
+int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_firpfbch2_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
@@ -2349,8 +2349,8 @@ int yagi_hip_firpfbch2_crcf_create(size_t M, size_t m, const float *h, yagi_hip_
     YG_TRY(o->syn_hist.init((int)((4 * m - 1) * M), nullptr));
     *q = o.release();
     return YAGI_OK;
-}
-int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
@@ -2361,9 +2361,9 @@ int yagi_hip_firpfbch2_crcf_create_kaiser(size_t M, size_t m, float as_, yagi_hi
     for (float v : hf) hsum += v;
     for (float &v : hf) v = v * (float)M / hsum;
     return yagi_hip_firpfbch2_crcf_create(M, m, hf.data(), q);
-}
+} catch (...) { return ::yagi::api_exception(); }
 // prototype of the matching synthesizer: kaiser(2Mm+1, 0.5/M, as), scaled to sum M (analyzer: cutoff 1/M)
-int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) {
+int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float as_, yagi_hip_firpfbch2_crcf *q) try {
     CHECK_PTR(q);
     *q = nullptr;
     if (M < 2 || (M & 1)) return fail(YAGI_ERR_CONFIG, "number of channels must be greater than 2 and even");
@@ -2374,23 +2374,23 @@ int yagi_hip_firpfbch2_crcf_create_kaiser_synthesizer(size_t M, size_t m, float 
     for (float v : hf) hsum += v;
     for (float &v : hf) v = v * (float)M / hsum;
     return yagi_hip_firpfbch2_crcf_create(M, m, hf.data(), q);
-}
-int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q) { delete q; return YAGI_OK; }
-int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_destroy(yagi_hip_firpfbch2_crcf q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_set_stream(yagi_hip_firpfbch2_crcf q, yagi_stream_t s) try {
     CHECK_Q(q);
     if (q->st == to_stream(s)) return YAGI_OK;      // unchanged: no host synchronisation
     YG_HIP(hipStreamSynchronize(q->st));
     q->st = to_stream(s);
     return YAGI_OK;
-}
-int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_reset(yagi_hip_firpfbch2_crcf q) try {
     CHECK_Q(q);
     q->step = 0;
     q->syn_step = 0;
     YG_TRY(q->hist.reset(q->st));
     return q->syn_hist.reset(q->st);
-}
-int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2400,8 +2400,8 @@ int yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(yagi_hip_firpfbch2_crcf q, c
                                 q->syn_step, y, nsteps, q->st));
     q->syn_step += nsteps;
     return q->syn_hist.advance(x, nsteps * (size_t)q->M, q->st);
-}
-int yagi_hip_firpfbch2_crcf_synthesizer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_synthesizer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2412,9 +2412,9 @@ int yagi_hip_firpfbch2_crcf_synthesizer_execute(yagi_hip_firpfbch2_crcf q, const
     YG_TRY(upload(q->ws.x.p, x, in_bytes, q->st));
     YG_TRY(yagi_hip_firpfbch2_crcf_synthesizer_execute_dev(q, q->ws.x.as<cf32>(), nsteps, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, out_bytes, q->st);
-}
+} catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps,
-                                                       int rank, int nranks, yagi_cf32 *y) {
+                                                       int rank, int nranks, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2426,11 +2426,11 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(yagi_hip_firpfbch2_crcf q
     q->step += nsteps;
     if (written) { q->hist.flip(); return YAGI_OK; }         // the kernel's last workgroup wrote the next history
     return q->hist.advance(x, nsteps * (size_t)(q->M / 2), q->st);
-}
-int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_analyzer_execute_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) try {
     return yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(q, x, nsteps, 0, 1, y);
-}
-int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) {
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(x);
@@ -2441,11 +2441,11 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute(yagi_hip_firpfbch2_crcf q, const ya
     YG_TRY(upload(q->ws.x.p, x, bin, q->st));
     YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_dev(q, q->ws.x.as<cf32>(), nsteps, q->ws.y.as<cf32>()));
     return download(y, q->ws.y.p, bout, q->st);
-}
+} catch (...) { return ::yagi::api_exception(); }
 // sub-bands sharded over the ranks of `comm`: shard kernel (this stream) -> RCCL all-gather -> assemble (the
 // communicator's stream), chunk by chunk so chunk k's exchange runs beside chunk k+1's kernel
 int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf q, const yagi_cf32 *x, size_t nsteps,
-                                                         yagi_hip_comm comm, int nchunks, yagi_cf32 *y) {
+                                                         yagi_hip_comm comm, int nchunks, yagi_cf32 *y) try {
     CHECK_Q(q);
     if (!comm) return fail(YAGI_ERR_CONFIG, "null communicator");
     if (nsteps == 0) return YAGI_OK;
@@ -2485,14 +2485,14 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf
     YG_HIP(hipEventRecord(comm->done, comm->st));
     YG_HIP(hipStreamWaitEvent(q->st, comm->done, 0));
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered, size_t nsteps, size_t M, int nranks,
-                                         yagi_cf32 *y, yagi_stream_t s) {
+                                         yagi_cf32 *y, yagi_stream_t s) try {
     if (nsteps == 0) return YAGI_OK;
     CHECK_PTR(gathered);
     CHECK_PTR(y);
     return launch_firpfbch2_assemble(gathered, nsteps, (int)M, nranks, y, to_stream(s));
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 }  // extern "C"
 
@@ -2705,7 +2705,7 @@ struct MsResamp2Obj {
     struct yagi_hip_resamp2_##K##_s : Resamp2Obj<KT> {};                                            \
     struct yagi_hip_msresamp2_##K##_s : MsResamp2Obj<KT> {};                                        \
     extern "C" {                                                                                    \
-    int yagi_hip_resamp2_##K##_create(const float *hf, size_t m, float f0, yagi_hip_resamp2_##K *q) { \
+    int yagi_hip_resamp2_##K##_create(const float *hf, size_t m, float f0, yagi_hip_resamp2_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         CHECK_PTR(hf);                                                                              \
@@ -2713,8 +2713,8 @@ struct MsResamp2Obj {
         YG_TRY(o->init(hf, m, f0));                                                                 \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_create_kaiser(size_t m, float f0, float as_, yagi_hip_resamp2_##K *q) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_create_kaiser(size_t m, float f0, float as_, yagi_hip_resamp2_##K *q) try { \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (m < 2) return fail(YAGI_ERR_CONFIG, "filter semi-length must be at least 2");           \
@@ -2725,9 +2725,9 @@ struct MsResamp2Obj {
         YG_TRY(design_kaiser(4 * m + 1, 0.25f, as_ > 0.0f ? as_ : 1e-3f, 0.0f, hf));                \
         for (float &v : hf) v *= 0.5f;                 /* sinc(t/2) w(t) has centre 1: half-band = centre 1/2 */ \
         return yagi_hip_resamp2_##K##_create(hf.data(), m, f0, q);                                  \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_destroy(yagi_hip_resamp2_##K q) { delete q; return YAGI_OK; }        \
-    int yagi_hip_resamp2_##K##_clone(yagi_hip_resamp2_##K q, yagi_hip_resamp2_##K *out) {           \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_destroy(yagi_hip_resamp2_##K q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); } \
+    int yagi_hip_resamp2_##K##_clone(yagi_hip_resamp2_##K q, yagi_hip_resamp2_##K *out) try {       \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -2735,45 +2735,45 @@ struct MsResamp2Obj {
         YG_TRY(q->clone_into(*o));                                                                  \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_reset(yagi_hip_resamp2_##K q) { CHECK_Q(q); return q->reset(); }     \
-    int yagi_hip_resamp2_##K##_set_stream(yagi_hip_resamp2_##K q, yagi_stream_t s) {                \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_reset(yagi_hip_resamp2_##K q) try { CHECK_Q(q); return q->reset(); } catch (...) { return ::yagi::api_exception(); } \
+    int yagi_hip_resamp2_##K##_set_stream(yagi_hip_resamp2_##K q, yagi_stream_t s) try {            \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_set_scale(yagi_hip_resamp2_##K q, C scale) { CHECK_Q(q); q->scale = scale; return YAGI_OK; } \
-    int yagi_hip_resamp2_##K##_get_scale(yagi_hip_resamp2_##K q, C *scale) {                        \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_set_scale(yagi_hip_resamp2_##K q, C scale) try { CHECK_Q(q); q->scale = scale; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); } \
+    int yagi_hip_resamp2_##K##_get_scale(yagi_hip_resamp2_##K q, C *scale) try {                    \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(scale);                                                                           \
         *scale = q->scale;                                                                          \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_get_delay(yagi_hip_resamp2_##K q, size_t *delay) {                   \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_get_delay(yagi_hip_resamp2_##K q, size_t *delay) try {               \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(delay);                                                                           \
         *delay = 2 * (size_t)q->m - 1;                                                              \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) try { \
         CHECK_Q(q);                                                                                 \
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->block_host(mode, x, nx, y);                                                       \
-    }                                                                                               \
-    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) try { \
         CHECK_Q(q);                                                                                 \
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, nx, y, q->out_count(mode, nx));                                            \
         return q->block_dev(mode, x, nx, y);                                                        \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
-                                             const float *hf_all, yagi_hip_msresamp2_##K *q) {      \
+                                             const float *hf_all, yagi_hip_msresamp2_##K *q) try {  \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         if (num_stages) { CHECK_PTR(m_stage); CHECK_PTR(hf_all); }                                  \
@@ -2781,9 +2781,9 @@ struct MsResamp2Obj {
         YG_TRY(o->init(interp != 0, num_stages, m_stage, hf_all));                                  \
         *q = o.release();                                                                           \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_msresamp2_##K##_create(int interp, size_t num_stages, float fc, float f0, float as_, \
-                                        yagi_hip_msresamp2_##K *q) {                                \
+                                        yagi_hip_msresamp2_##K *q) try {                            \
         CHECK_PTR(q);                                                                               \
         *q = nullptr;                                                                               \
         std::vector<size_t> ms;                                                                     \
@@ -2796,9 +2796,9 @@ struct MsResamp2Obj {
             all.insert(all.end(), hf.begin(), hf.end());                                            \
         }                                                                                           \
         return yagi_hip_msresamp2_##K##_create_taps(interp, num_stages, ms.data(), all.data(), q);  \
-    }                                                                                               \
-    int yagi_hip_msresamp2_##K##_destroy(yagi_hip_msresamp2_##K q) { delete q; return YAGI_OK; }    \
-    int yagi_hip_msresamp2_##K##_clone(yagi_hip_msresamp2_##K q, yagi_hip_msresamp2_##K *out) {     \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_msresamp2_##K##_destroy(yagi_hip_msresamp2_##K q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); } \
+    int yagi_hip_msresamp2_##K##_clone(yagi_hip_msresamp2_##K q, yagi_hip_msresamp2_##K *out) try { \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
@@ -2815,44 +2815,44 @@ struct MsResamp2Obj {
         }                                                                                           \
         *out = o.release();                                                                         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_msresamp2_##K##_reset(yagi_hip_msresamp2_##K q) {                                  \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_msresamp2_##K##_reset(yagi_hip_msresamp2_##K q) try {                              \
         CHECK_Q(q);                                                                                 \
         for (auto &s : q->stage) YG_TRY(s->reset());                                                \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_msresamp2_##K##_set_stream(yagi_hip_msresamp2_##K q, yagi_stream_t s) {            \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_msresamp2_##K##_set_stream(yagi_hip_msresamp2_##K q, yagi_stream_t s) try {        \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         for (auto &g : q->stage) g->st = q->st;                                                     \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_msresamp2_##K##_get_params(yagi_hip_msresamp2_##K q, int *interp, size_t *num_stages, \
-                                            float *delay, size_t *m_stage) {                        \
+                                            float *delay, size_t *m_stage) try {                    \
         CHECK_Q(q);                                                                                 \
         if (interp) *interp = q->interp ? 1 : 0;                                                    \
         if (num_stages) *num_stages = q->num_stages;                                                \
         if (delay) *delay = q->delay();                                                             \
         if (m_stage) for (size_t i = 0; i < q->num_stages; ++i) m_stage[i] = q->m_stage[i];         \
         return YAGI_OK;                                                                             \
-    }                                                                                               \
-    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) try { \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->block_host(x, n, y);                                                              \
-    }                                                                                               \
-    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) { \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) try { \
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, q->interp ? n : n * q->rate, y, q->interp ? n * q->rate : n);              \
         return q->block_dev(x, n, y);                                                               \
-    }                                                                                               \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     }
 
 YAGI_RESAMP2_IMPL(rrrf, RRRF, float, float)

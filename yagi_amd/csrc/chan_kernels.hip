@@ -1213,11 +1213,120 @@ firpfbch2_syn_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     }
 }
 
+// Column-sliding firpfbch2 synthesizer (M in {8..256}, m in {2, 4}): firpfbch_syn_col_kernel with a ring of 4m steps per
+// column.  Column c of the inverse-transformed steps feeds output i = c mod M/2 -- on the steps whose parity f selects
+// its half (b = i + f M/2 = c) -- with the taps of lag k: hk[k] = h[i + (k & 1) M/2 + (k >> 1) M] (lag 2n: first sum, lag
+// 2n + 1: second sum; added in lag order like the tiled kernel).  For M >= 128 a wave is all-lower or all-upper half:
+// the two halves of a workgroup alternate, nobody diverges.  A run starts with W = 8 (m = 2) or 16 warm-up steps.
+template <int P2, int LGM>
+__global__ void __launch_bounds__(256)
+firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
+                         const float *__restrict__ h, const float2 *__restrict__ twM,
+                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run) {
+    constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2;
+    constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int G = 256 / M;
+    constexpr int nq = G * kColHalf, lgnq = 8 - LGM + 3;
+    constexpr int pitch = col_pitch(M, nq);
+    constexpr int W = P2 <= 8 ? 8 : 16;                          // warm-up steps per run (>= P2 - 1)
+    float2 *va = reinterpret_cast<float2 *>(smem);
+    float2 *vb = va + nq * pitch;
+    float2 *twl = vb + nq * pitch;
+    const int g = threadIdx.x >> lgM, c = threadIdx.x & (M - 1);
+    const int i = c & (M2 - 1), hi = c >> (LGM - 1);
+    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    float hk[P2];
+#pragma unroll
+    for (int k = 0; k < P2; ++k) hk[k] = 0.5f * h[i + (k & 1) * M2 + (k >> 1) * M];
+    const int hist_len = (P2 - 1) * M;
+    const long long x_len = (long long)nsteps * M;
+    const long long s_begin = ((long long)blockIdx.x * G + g) * run;
+    const long long left = (long long)nsteps - s_begin;
+    const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
+    const int par = (int)((step0 + (unsigned long long)s_begin) & 1ull) ^ hi;   // this lane's outputs: steps t with (t + par) even
+    float2 w[P2];
+#pragma unroll
+    for (int n = 0; n < P2; ++n) w[n] = make_float2(0.f, 0.f);
+    auto half_tile = [&](int t, auto slot0) {
+        constexpr int S0 = decltype(slot0)::value;
+#pragma unroll
+        for (int j = 0; j < kColHalf; ++j) {
+            const long long s = s_begin + t + j;
+            va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, s * M + c, x_len)
+                                                                 : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
+        __syncthreads();
+        const float2 *res = vb;
+        if constexpr (R1 > 1) {
+            stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
+            __syncthreads();
+            res = va;
+        }
+#pragma unroll
+        for (int j = 0; j < kColHalf; ++j) {
+            w[(S0 + j) % P2] = res[(g * kColHalf + j) * pitch + c];
+            if (((j + par) & 1) == 0 && t + j >= 0 && t + j < nvalid) {      // t is even: parity of the step = parity of j
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < P2; ++k) {
+                    const float2 sv = w[(S0 + j - k + 4 * P2) % P2];
+                    acc.x = fmaf(sv.x, hk[k], acc.x);
+                    acc.y = fmaf(sv.y, hk[k], acc.y);
+                }
+                y[(s_begin + t + j) * M2 + i] = acc;
+            }
+        }
+        __syncthreads();                             // the next half tile overwrites va / vb
+    };
+    if constexpr (P2 <= 8) {
+        for (int t0 = -W; t0 < run; t0 += kColHalf) half_tile(t0, std::integral_constant<int, 0>{});
+    } else {
+        for (int t0 = -W; t0 < run; t0 += kColTile) {
+            half_tile(t0, std::integral_constant<int, 0>{});
+            half_tile(t0 + kColHalf, std::integral_constant<int, kColHalf>{});
+        }
+    }
+}
+
+template <int P2, int LGM>
+static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM, uint64_t step0,
+                                    cf32 *y, size_t nsteps, hipStream_t st) {
+    constexpr int M = 1 << LGM;
+    const int G = 256 / M;
+    size_t run = nsteps / ((size_t)YG_COL_WGS * G);
+    run = run / kColTile * kColTile;
+    if (run < (size_t)kColTile) run = kColTile;
+    if (run > 256) run = 256;
+    const size_t ngroups = (nsteps + run - 1) / run;
+    const size_t nblk = (ngroups + G - 1) / G;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
+    firpfbch2_syn_col_kernel<P2, LGM><<<(unsigned)nblk, 256, lds, st>>>(
+        reinterpret_cast<const float2 *>(hist), reinterpret_cast<const float2 *>(x), h,
+        reinterpret_cast<const float2 *>(twM), (unsigned long long)step0, reinterpret_cast<float2 *>(y), nsteps, (int)run);
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
 int launch_firpfbch2_syn(const cf32 *hist, int hist_len, const cf32 *x, const float *h, int M, int m,
                          const cf32 *twM, uint64_t step0, cf32 *y, size_t nsteps, hipStream_t st) {
     if (nsteps == 0) return YAGI_OK;
     const int p = 2 * m, back = 2 * p - 1;
     if (hist_len != back * M) return fail(YAGI_ERR_INTERNAL, "firpfbch2 synthesizer: bad history length");
+    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && (m == 2 || m == 4) && nsteps >= 64) {
+#define YG_SYN2_CASE(PP)                                                                                     \
+    (M == 8 ? launch_firpfbch2_syn_col<PP, 3>(hist, x, h, twM, step0, y, nsteps, st)                         \
+     : M == 16 ? launch_firpfbch2_syn_col<PP, 4>(hist, x, h, twM, step0, y, nsteps, st)                      \
+     : M == 32 ? launch_firpfbch2_syn_col<PP, 5>(hist, x, h, twM, step0, y, nsteps, st)                      \
+     : M == 64 ? launch_firpfbch2_syn_col<PP, 6>(hist, x, h, twM, step0, y, nsteps, st)                      \
+     : M == 128 ? launch_firpfbch2_syn_col<PP, 7>(hist, x, h, twM, step0, y, nsteps, st)                     \
+                : launch_firpfbch2_syn_col<PP, 8>(hist, x, h, twM, step0, y, nsteps, st))
+        return m == 2 ? YG_SYN2_CASE(8) : YG_SYN2_CASE(16);
+#undef YG_SYN2_CASE
+    }
     int S = 4096 / M;
     if (S < 1) S = 1;
     auto need = [&](int s) { return (2 * (size_t)(s + back) * M + (size_t)M) * sizeof(float2); };

@@ -80,7 +80,7 @@ using namespace yagi;
 
 extern "C" {
 
-int yagi_hip_comm_unique_id(unsigned char *id) {
+int yagi_hip_comm_unique_id(unsigned char *id) try {
     if (!id) return fail(YAGI_ERR_CONFIG, "null pointer argument");
     YG_TRY(rccl_ready());
     static_assert(NCCL_UNIQUE_ID_BYTES == YAGI_HIP_COMM_ID_BYTES, "unique id size");
@@ -88,9 +88,9 @@ int yagi_hip_comm_unique_id(unsigned char *id) {
     YG_NCCL(rccl().GetUniqueId(&u));
     std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_comm_create(const unsigned char *id, int rank, int nranks, yagi_hip_comm *out) {
+int yagi_hip_comm_create(const unsigned char *id, int rank, int nranks, yagi_hip_comm *out) try {
     if (!id || !out) return fail(YAGI_ERR_CONFIG, "null pointer argument");
     *out = nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(YAGI_ERR_CONFIG, "bad rank %d of %d", rank, nranks);
@@ -111,9 +111,9 @@ int yagi_hip_comm_create(const unsigned char *id, int rank, int nranks, yagi_hip
     YG_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     *out = c.release();
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_comm_destroy(yagi_hip_comm c) {
+int yagi_hip_comm_destroy(yagi_hip_comm c) try {
     if (!c) return YAGI_OK;
     if (c->st) (void)hipStreamSynchronize(c->st);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -122,21 +122,21 @@ int yagi_hip_comm_destroy(yagi_hip_comm c) {
     if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(static_cast<ncclComm_t>(c->nccl));
     delete c;
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 
-int yagi_hip_comm_rank(yagi_hip_comm c, int *rank, int *nranks) {
+int yagi_hip_comm_rank(yagi_hip_comm c, int *rank, int *nranks) try {
     if (!c) return fail(YAGI_ERR_CONFIG, "null communicator");
     if (rank) *rank = c->rank;
     if (nranks) *nranks = c->nranks;
     return YAGI_OK;
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 int yagi_hip_comm_all_gather_dev(yagi_hip_comm c, const void *send_dev, void *recv_dev, size_t bytes_per_rank,
-                                 yagi_stream_t s) {
+                                 yagi_stream_t s) try {
     if (!c) return fail(YAGI_ERR_CONFIG, "null communicator");
     if (bytes_per_rank == 0) return YAGI_OK;
     if (!send_dev || !recv_dev) return fail(YAGI_ERR_CONFIG, "null pointer argument");
     return comm_all_gather(c, send_dev, recv_dev, bytes_per_rank, to_stream(s));
-}
+} catch (...) { return ::yagi::api_exception(); }
 
 }  // extern "C"
