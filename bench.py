@@ -439,6 +439,38 @@ def main():
             "parity_rel_l2_vs_f64": parity,
         }
         out.update(extras)
+    # N > 1: the one path with a real exchange step (C5: firpfbch2 sub-bands sharded over the ranks, RCCL all-gather,
+    # SURVEY 8e) rides along as an untimed extra so the scaling run measures it on real xGMI; `value` above is unaffected.
+    # A watchdog prints the main line and leaves if the leg does not come back (a collective that never completes).
+    if world > 1 and not args.no_extras:
+        import copy
+        import threading
+        main_line = json.dumps(out) if rank == 0 else None
+
+        def bail():
+            if rank == 0:
+                o = json.loads(main_line)
+                o["c5_sharded"] = {"error": "no result within 180 s (watchdog)"}
+                print(json.dumps(o), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(180.0, bail)
+        dog.daemon = True
+        dog.start()
+        c5 = None
+        try:
+            x = y = None                             # 4 GiB back before the C5 buffers are made
+            torch.cuda.empty_cache()
+            import bench_c5
+            a5 = copy.copy(args)
+            a5.steps, a5.warmup, a5.prewarm_ms = min(args.steps, 5), 2, 0.0
+            c5 = bench_c5.run(a5, rank, world, dev)
+        except Exception as e:                       # reported, never fatal for the headline line
+            c5 = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            out["c5_sharded"] = c5
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             out["cpu_baseline"] = cpu_baseline(oracle.fir_design_kaiser(TAPS, 0.2, 60.0), scale,
