@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiling target: launch each selected kernel a few times (for rocprofv3 --pmc / --kernel-trace).
 usage: python3 tools/prof_target.py [fused fused2 fir2 fir3 fft fft_big chan1 chan2 rrrf63 rrrf256 cccf256
-       decim4x257 decim8x513 interp4 fft16384 fft65536] """
+       decim4x65 decim4x257 decim8x513 interp4 syn2 resamp2 fft16384 fft65536 fft1048576] """
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -51,14 +51,21 @@ for w in what:
         q = ya.FirFilter(kind, hh); q.set_stream(st.cuda_stream)
         xin, yout, cnt = (x.view(torch.float32), y.view(torch.float32), n) if kind == "rrrf" else (x, y, n)
         fn = lambda q=q, xin=xin, yout=yout, cnt=cnt: q.execute_block_dev(xin, cnt, yout)
-    elif w in ("decim4x257", "decim8x513"):
-        M, L = (4, 257) if w == "decim4x257" else (8, 513)
+    elif w in ("decim4x65", "decim4x257", "decim8x513"):
+        M, L = {"decim4x65": (4, 65), "decim4x257": (4, 257), "decim8x513": (8, 513)}[w]
         d = ya.FirDecimationFilter("crcf", M, ya.fir_design_kaiser(L, 0.4 / M, 60.0)); d.set_stream(st.cuda_stream)
         fn = lambda d=d, M=M: d.execute_block_dev(x, n // M, y)
     elif w == "interp4":
         fi = ya.FirInterpolationFilter.new_kaiser("crcf", 4, 8, 60.0); fi.set_stream(st.cuda_stream)
         fn = lambda fi=fi: fi.execute_block_dev(x, n // 4, y)
-    elif w in ("fft16384", "fft65536"):
+    elif w == "syn2":
+        c = ya.FirPfbCh2.new_kaiser_synthesizer(256, 4, 60.0); c.set_stream(st.cuda_stream)
+        fn = lambda c=c: c.synthesizer_execute_dev(x, n // 256, y)
+    elif w == "resamp2":
+        r2 = ya.Resamp2.new("crcf", 12, 0.0, 60.0)
+        r2.set_stream(st.cuda_stream)
+        fn = lambda r2=r2: r2.execute_block_dev(r2.DECIM, x, n, y)
+    elif w in ("fft16384", "fft65536", "fft1048576"):
         N = int(w[3:])
         p = ya.Fft(N, ya.Direction.Forward)
         fn = lambda p=p, N=N: p.run_batch_dev(x, y, n // N, st.cuda_stream)

@@ -187,11 +187,13 @@ constexpr int kColHalf = 8;
 
 // M = 2^LGM is a template parameter so that only the two radix passes M needs are instantiated (with a run-time
 // plan the register allocation is that of the widest radix: 200 VGPRs).
-template <int P, int LGM>
+// FULL: every workgroup of the launch holds G * run frames (the tail, if any, is a second launch of one workgroup with
+// FULL = false and wg0 = its index; hist_next goes to the last launch only).
+template <int P, int LGM, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                     const float *__restrict__ h, const float2 *__restrict__ twM,
-                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next) {
+                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next, unsigned wg0) {
     constexpr int M = 1 << LGM, lgM = LGM;
     chan_write_next_hist(hist, (P - 1) * M, x, nframes * (size_t)M, hist_next);
     // 8, 16: one pass; 32 = 8 x 4, 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
@@ -212,10 +214,9 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     const long long x_len = (long long)nframes * M;
     // one workgroup = G consecutive runs of `run` frames (no grid-stride loop); all frame indices below are
     // 32-bit offsets from the workgroup's first frame
-    const long long wg_first = (long long)blockIdx.x * G * run;
+    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
     const long long wg_left = (long long)nframes - wg_first;                     // > 0
     const int wg_frames = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
-    const bool full = wg_frames == G * run;          // block-uniform: no per-frame checks anywhere
     auto group_frames = [&](int gq) {                // frames of group gq that exist
         const int v = wg_frames - gq * run;
         return v < 0 ? 0 : (v > run ? run : v);
@@ -228,10 +229,17 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     for (int n = 1; n < P; ++n)
         w[P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + c, x_len);
     float2 xa[kColHalf], xb[kColHalf];               // the next two half tiles of this column, in flight
+    // A full workgroup addresses its samples and outputs through buffer descriptors: one VGPR byte offset per lane,
+    // the frame steps in SGPRs -- no 64-bit address arithmetic, no per-frame checks.
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + wg_first * M, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + wg_first * M, 0xffffffffu);
+    const unsigned vx = 8u * ((unsigned)(g * run) * M + c);
     auto load8 = [&](float2 (&d)[kColHalf], int t) {
 #pragma unroll
-        for (int j = 0; j < kColHalf; ++j)
-            d[j] = (full || t + j < nvalid) ? xg[(unsigned)(t + j) << lgM] : make_float2(0.f, 0.f);
+        for (int j = 0; j < kColHalf; ++j) {
+            if constexpr (FULL) d[j] = buf_ld(rx, vx, 8u * ((unsigned)(t + j) << lgM));
+            else d[j] = (t + j < nvalid) ? xg[(unsigned)(t + j) << lgM] : make_float2(0.f, 0.f);
+        }
     };
     float2 *yb = y + wg_first * M;
     // FIR over 8 frames of the column (ring slots static: run, t0 are multiples of 16 and P divides 16), then
@@ -267,8 +275,11 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
         for (int i = 0; i < kColHalf; ++i) {
             const int e = threadIdx.x + 256 * i;
             const int q = e >> lgM, k = e & (M - 1);
-            const int gq = q / kColHalf, fr = t + (q - gq * kColHalf);
-            if (full || fr < group_frames(gq)) yb[((unsigned)(gq * run + fr) << lgM) + k] = res[q * pitch + k];
+            const int gq = q / kColHalf, fr = q - gq * kColHalf;
+            if constexpr (FULL)
+                buf_st(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), res[q * pitch + k]);
+            else if (t + fr < group_frames(gq))
+                yb[((unsigned)(gq * run + t + fr) << lgM) + k] = res[q * pitch + k];
         }
         __syncthreads();
     };
@@ -294,19 +305,27 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const size_t ngroups = (nframes + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    const unsigned grid = (unsigned)nblk;
     const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P, LGM>),
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P, LGM, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_col_kernel<P, LGM, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    firpfbch_col_kernel<P, LGM><<<grid, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
-                                                       reinterpret_cast<const float2 *>(x), h,
-                                                       reinterpret_cast<const float2 *>(twM),
-                                                       reinterpret_cast<float2 *>(y), nframes, (int)run,
-                                                       reinterpret_cast<float2 *>(hist_next));
+    // workgroups that hold G * run frames take the check-free kernel; a partial last workgroup is a launch of its own
+    const size_t nfull = nframes / ((size_t)G * run);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
+    if (nfull)
+        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
+                                                                            nfull == nblk ? fn : nullptr, 0u);
+    YG_LAUNCH_CHECK();
+    if (nfull < nblk)
+        firpfbch_col_kernel<P, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
+                                                                                      fn, (unsigned)nfull);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }

@@ -134,4 +134,23 @@ __device__ __forceinline__ void batched_for(int total, Load load, Store store) {
     else batched_for_b<NT, 8, false>(total, load, store);
 }
 
+// buffer-addressed 8-byte accesses: one VGPR byte offset per lane, the steps of an unrolled run in SGPRs / immediates (the
+// flat form spends ~3 VALU + a carry-hazard nop on every 64-bit address); an access at or beyond `bytes` reads zero /
+// is dropped, which makes the tail checks of a partial tile free
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
+    v2u_t q;
+    q.x = __float_as_uint(v.x);
+    q.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
+}
+
+
 }  // namespace yagi

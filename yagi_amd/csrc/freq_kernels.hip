@@ -62,22 +62,6 @@ constexpr unsigned kFreqLdsFloat2 = kOffG + 144;         // 40 064 B -> 4 workgr
 constexpr unsigned kOffPart = 768;                       // partial sums behind d (inside the exchange buffer), 6 float2 per item
 constexpr int kTriS = 40;                                // taps per work item
 
-// buffer-addressed 8-byte accesses: one VGPR byte offset shared by the 16 accesses of a lane, the steps in SGPRs
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-}
-__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
-    v2u_t q;
-    q.x = __float_as_uint(v.x);
-    q.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
-}
-
 // sample m of d at float2 index m + 2 (m >> 2): 16 B of padding after every 4 samples
 __device__ __forceinline__ unsigned pidx4(unsigned m) { return m + ((m >> 2) << 1); }
 // first item of chunk c: sum_{c' < c} (64 - 10 c')
