@@ -799,12 +799,15 @@ __device__ unsigned long long g_chan_stamps[2048 * 4 * 12];
 // ---------------------------------------------------------------------------------------------
 // M = 2^LGM is a template parameter (see firpfbch_col_kernel); SHARDED = a rank's sub-band shard (R > 1: fold to the
 // residue class, then a run-time planned M/R-point transform), otherwise two static radix passes.
-template <int P, int LGM, bool SHARDED>
+// FULL: every workgroup of the launch holds G * run steps -- samples and outputs go through buffer descriptors (one
+// VGPR byte offset per lane, the steps in SGPRs / immediates: no 64-bit address arithmetic, no per-step checks); a
+// partial last workgroup is a launch of its own with FULL = false and wg0 = its index.
+template <int P, int LGM, bool SHARDED, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM, Pow2Plan plan,
                      int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */,
-                     float2 *__restrict__ hist_next) {
+                     float2 *__restrict__ hist_next, unsigned wg0) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
     chan_write_next_hist(hist, hist_len, x, nsteps * (size_t)M2, hist_next);
@@ -831,10 +834,9 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     const float invM = 1.0f / (float)M;
     const long long x_len = (long long)nsteps * M2;
     // one workgroup = G consecutive runs of `run` steps; step indices below are 32-bit offsets from its first
-    const long long wg_first = (long long)blockIdx.x * G * run;
+    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
     const long long wg_left = (long long)nsteps - wg_first;
     const int wg_steps = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
-    const bool full = wg_steps == G * run;
     auto group_steps = [&](int gq) {
         const int v = wg_steps - gq * run;
         return v < 0 ? 0 : (v > run ? run : v);
@@ -849,10 +851,15 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
         w[(P - n) % P] = load_hist(hist, hist_len, x, (s_begin - 2 * n + bpar) * M2 + pos, x_len);
     constexpr int kPairs = kColHalf / 2;                                 // 4 samples feed 8 steps
     float2 xa[kPairs], xb[kPairs];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + wg_first * M2, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + wg_first * Mr, 0xffffffffu);
+    const unsigned vx = 8u * ((unsigned)(g * run + bpar) * M2 + pos);
     auto load4 = [&](float2 (&d)[kPairs], int t /* first step of the half tile */) {
 #pragma unroll
-        for (int kk = 0; kk < kPairs; ++kk)
-            d[kk] = (full || t + 2 * kk + bpar < nvalid) ? xg[(unsigned)(t / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+        for (int kk = 0; kk < kPairs; ++kk) {
+            if constexpr (FULL) d[kk] = buf_ld(rx, vx, 8u * ((unsigned)(t / 2 + kk) << lgM));
+            else d[kk] = (t + 2 * kk + bpar < nvalid) ? xg[(unsigned)(t / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+        }
     };
     float2 *yb = y + wg_first * Mr;
     auto half_tile = [&](float2 (&xin)[kPairs], int t, auto slot0) {
@@ -910,9 +917,12 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             if constexpr (R1 >= 8 && M / R1 >= 16) {
                 // last pass straight from registers to y: 16-lane runs of 128 contiguous bytes (M = 256)
                 stockham_last_pass_out<R1, +1>(vb, M, nq, twl, 1, true, pitch, [&](int q, int k, float2 v) {
-                    const int gq = q / kColHalf, sr = t + (q - gq * kColHalf);
-                    if (full || sr < group_steps(gq))
-                        yb[(size_t)(gq * run + sr) * M + k] = make_float2(v.x * invM, v.y * invM);
+                    const int gq = q / kColHalf, sl = q - gq * kColHalf;
+                    if constexpr (FULL)
+                        buf_st(ry, 8u * (((unsigned)(gq * run + sl) << lgM) + k), 8u * ((unsigned)t << lgM),
+                               make_float2(v.x * invM, v.y * invM));
+                    else if (t + sl < group_steps(gq))
+                        yb[(size_t)(gq * run + t + sl) * M + k] = make_float2(v.x * invM, v.y * invM);
                 });
                 YG_CSTAMP(7);
                 YG_CSTAMP(8);
@@ -928,10 +938,14 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
         }
         for (int e = threadIdx.x; e < nq * Mr; e += 256) {
             const int q = e >> lgMr, k = e & (Mr - 1);
-            const int gq = q / kColHalf, sr = t + (q - gq * kColHalf);
-            if (full || sr < group_steps(gq)) {
+            const int gq = q / kColHalf, sl = q - gq * kColHalf;
+            if constexpr (FULL) {
                 const float2 v = res[q * pitch + k];
-                yb[(size_t)(gq * run + sr) * Mr + k] = make_float2(v.x * invM, v.y * invM);
+                buf_st(ry, 8u * ((unsigned)(gq * run + sl) * Mr + k), 8u * ((unsigned)t * Mr),
+                       make_float2(v.x * invM, v.y * invM));
+            } else if (t + sl < group_steps(gq)) {
+                const float2 v = res[q * pitch + k];
+                yb[(size_t)(gq * run + t + sl) * Mr + k] = make_float2(v.x * invM, v.y * invM);
             }
         }
         YG_CSTAMP(7);
@@ -959,19 +973,33 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const size_t ngroups = (nsteps + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    const unsigned grid = (unsigned)nblk;
     const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
-    float2 *fy = reinterpret_cast<float2 *>(y);
-    if (nranks > 1)
-        firpfbch2_col_kernel<P, LGM, true><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, make_pow2_plan(M / nranks),
-                                                                  rank, nranks, fy, nsteps, (int)run,
-                                                                  reinterpret_cast<float2 *>(hist_next));
-    else
-        firpfbch2_col_kernel<P, LGM, false><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, Pow2Plan{0, {0}}, 0, 1,
-                                                                   fy, nsteps, (int)run, reinterpret_cast<float2 *>(hist_next));
-    YG_LAUNCH_CHECK();
+    float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
+    // workgroups that hold G * run steps take the check-free kernel; a partial last workgroup is a launch of its own
+    const size_t nfull = nsteps / ((size_t)G * run);
+    const Pow2Plan plan = nranks > 1 ? make_pow2_plan(M / nranks) : Pow2Plan{0, {0}};
+    const int rk = nranks > 1 ? rank : 0, nr = nranks > 1 ? nranks : 1;
+    if (nfull) {
+        float2 *f1 = nfull == nblk ? fn : nullptr;
+        if (nranks > 1)
+            firpfbch2_col_kernel<P, LGM, true, true><<<(unsigned)nfull, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy,
+                                                                                      nsteps, (int)run, f1, 0u);
+        else
+            firpfbch2_col_kernel<P, LGM, false, true><<<(unsigned)nfull, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy,
+                                                                                       nsteps, (int)run, f1, 0u);
+        YG_LAUNCH_CHECK();
+    }
+    if (nfull < nblk) {
+        if (nranks > 1)
+            firpfbch2_col_kernel<P, LGM, true, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(
+                fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, (unsigned)nfull);
+        else
+            firpfbch2_col_kernel<P, LGM, false, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(
+                fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, (unsigned)nfull);
+        YG_LAUNCH_CHECK();
+    }
     return YAGI_OK;
 }
 
