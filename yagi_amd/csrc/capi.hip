@@ -380,6 +380,23 @@ static int make_stream_twiddles(DevBuf &buf) {
     return upload(buf.p, tab.data(), tab.size() * sizeof(cf32), nullptr);
 }
 
+// W_n^m for any m < n as a product of two exact entries: tab[m & 4095] = W_n^{m & 4095}, tab[4096 + (m >> 12)] = W_n^{4096 (m >> 12)}
+static int make_split_twiddles(size_t n, int dir, DevBuf &buf) {
+    const size_t nhi = (n + 4095) / 4096;
+    std::vector<cf32> tab(4096 + nhi);
+    const double s = dir == YAGI_FFT_FORWARD ? -1.0 : 1.0;
+    for (size_t j = 0; j < 4096; ++j) {
+        const double a = s * 2.0 * M_PI * (double)j / (double)n;
+        tab[j] = cf32{(float)std::cos(a), (float)std::sin(a)};
+    }
+    for (size_t j = 0; j < nhi; ++j) {
+        const double a = s * 2.0 * M_PI * (double)(4096 * j) / (double)n;
+        tab[4096 + j] = cf32{(float)std::cos(a), (float)std::sin(a)};
+    }
+    YG_TRY(buf.alloc(tab.size() * sizeof(cf32)));
+    return upload(buf.p, tab.data(), tab.size() * sizeof(cf32), nullptr);
+}
+
 static int fft_plan_init(FftPlan &p, size_t n, int dir) {
     if (n == 0) return fail(YAGI_ERR_CONFIG, "fft length must be greater than zero");
     if (dir != YAGI_FFT_FORWARD && dir != YAGI_FFT_BACKWARD) return fail(YAGI_ERR_CONFIG, "bad fft direction");
@@ -404,19 +421,7 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
             size_t chunk = ((size_t)1 << 23) / n;              // 64 MiB per scratch buffer (smaller chunks measured slower)
             if (chunk < 1) chunk = 1;
             YG_TRY(p.fs_scratch.alloc((n2 == 256 ? 1 : 2) * chunk * n * sizeof(cf32)));
-            const size_t nhi = n / 4096;
-            std::vector<cf32> tab(4096 + nhi);
-            const double s = dir == YAGI_FFT_FORWARD ? -1.0 : 1.0;
-            for (size_t j = 0; j < 4096; ++j) {
-                const double a = s * 2.0 * M_PI * (double)j / (double)n;
-                tab[j] = cf32{(float)std::cos(a), (float)std::sin(a)};
-            }
-            for (size_t j = 0; j < nhi; ++j) {
-                const double a = s * 2.0 * M_PI * (double)j / (double)nhi;
-                tab[4096 + j] = cf32{(float)std::cos(a), (float)std::sin(a)};
-            }
-            YG_TRY(p.fs_wsplit.alloc(tab.size() * sizeof(cf32)));
-            YG_TRY(upload(p.fs_wsplit.p, tab.data(), tab.size() * sizeof(cf32), nullptr));
+            YG_TRY(make_split_twiddles(n, dir, p.fs_wsplit));
             p.d.fs_n1 = 256;
             p.d.fs_n2 = (int)n2;
             p.d.fs_p1 = &p.fs_p1->d;
@@ -448,6 +453,9 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
             p.d.fs_p2 = &p.fs_p2->d;
             p.d.fs_scratch = p.fs_scratch.as<cf32>();
             p.d.fs_chunk = (int)chunk;
+            YG_TRY(make_split_twiddles(n, dir, p.fs_wsplit));
+            p.d.fs_wlo4 = p.fs_wsplit.as<cf32>();
+            p.d.fs_whi4 = p.fs_wsplit.as<cf32>() + 4096;
             auto small_pow2 = [](size_t v) { return v >= 64 && v <= 256 && (v & (v - 1)) == 0; };
             if (small_pow2(n1) && small_pow2(n2)) {            // two-launch form (fft_kernels.hip: fft_twopass_kernel)
                 YG_TRY(make_twiddles((int)n, dir, p.fs_wn));

@@ -213,7 +213,8 @@ bluestein_mul_kernel(float2 *__restrict__ f, const float2 *__restrict__ bf, int 
 // ---------------------------------------------------------------------------------------------
 template <bool TWIDDLE>
 __global__ void __launch_bounds__(256)
-fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int rows, int cols, double tw_step) {
+fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int rows, int cols,
+                     const float2 *__restrict__ wlo, const float2 *__restrict__ whi) {
     __shared__ float2 tile[32][33];
     const size_t mat = (size_t)blockIdx.z * rows * cols;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -223,10 +224,9 @@ fft_transpose_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, in
         const int r = r0 + ty + j, c = c0 + tx;
         if (r < rows && c < cols) {
             float2 v = in[mat + (size_t)r * cols + c];
-            if (TWIDDLE) {
-                double sn, cs;
-                sincospi(tw_step * (double)((long long)r * c), &sn, &cs);     // tw_step = -+2/n
-                v = cmul(v, make_float2((float)cs, (float)sn));
+            if (TWIDDLE) {                                  // W_n^{r c} = whi[m >> 12] wlo[m & 4095], m = r c < n
+                const unsigned m = (unsigned)r * (unsigned)c;
+                v = cmul(v, cmul(whi[m >> 12], wlo[m & 4095u]));
             }
             tile[ty + j][tx] = v;
         }
@@ -444,7 +444,7 @@ static int launch_fft_tile256(const FftPlanDev &p, const cf32 *in, cf32 *out, si
         } else {
             YG_TRY(launch_fft_batch(f2, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * 256, st));
             // D[k1][k2] -> X[k2][k1]
-            fft_transpose_kernel<false><<<dim3((unsigned)(n2 / 32), 8, nb), 256, 0, st>>>(s1, dst, 256, n2, 0.0);
+            fft_transpose_kernel<false><<<dim3((unsigned)(n2 / 32), 8, nb), 256, 0, st>>>(s1, dst, 256, n2, nullptr, nullptr);
             YG_LAUNCH_CHECK();
         }
     }
@@ -456,22 +456,22 @@ static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, 
     const size_t n = (size_t)p.n;
     const FftPlanDev &f1 = *p.fs_p1, &f2 = *p.fs_p2;
     float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch), *s1 = s0 + (size_t)p.fs_chunk * n;
-    const double tw_step = (p.dir == YAGI_FFT_FORWARD ? -2.0 : 2.0) / (double)n;
+    const float2 *wlo = reinterpret_cast<const float2 *>(p.fs_wlo4), *whi = reinterpret_cast<const float2 *>(p.fs_whi4);
     const unsigned g1 = (unsigned)((n1 + 31) / 32), g2 = (unsigned)((n2 + 31) / 32);
     for (size_t b0 = 0; b0 < batch; b0 += (size_t)p.fs_chunk) {
         const unsigned nb = (unsigned)((batch - b0) < (size_t)p.fs_chunk ? (batch - b0) : (size_t)p.fs_chunk);
         const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
         float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
         // x[n1][n2] -> A[n2][n1]
-        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(src, s0, n1, n2, 0.0);
+        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(src, s0, n1, n2, nullptr, nullptr);
         YG_LAUNCH_CHECK();
         YG_TRY(launch_fft_batch(f1, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n2, st));
         // B[n2][k1] -> C[k1][n2] with W_n^{n2 k1}
-        fft_transpose_kernel<true><<<dim3(g1, g2, nb), 256, 0, st>>>(s1, s0, n2, n1, tw_step);
+        fft_transpose_kernel<true><<<dim3(g1, g2, nb), 256, 0, st>>>(s1, s0, n2, n1, wlo, whi);
         YG_LAUNCH_CHECK();
         YG_TRY(launch_fft_batch(f2, reinterpret_cast<const cf32 *>(s0), reinterpret_cast<cf32 *>(s1), (size_t)nb * n1, st));
         // D[k1][k2] -> X[k2][k1]
-        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(s1, dst, n1, n2, 0.0);
+        fft_transpose_kernel<false><<<dim3(g2, g1, nb), 256, 0, st>>>(s1, dst, n1, n2, nullptr, nullptr);
         YG_LAUNCH_CHECK();
     }
     return YAGI_OK;

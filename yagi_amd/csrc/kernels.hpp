@@ -143,6 +143,7 @@ struct FftPlanDev {
     cf32 *fs_scratch = nullptr;      // 2 * fs_chunk * n points
     int fs_chunk = 0;
     const cf32 *fs_wn = nullptr;     // W_n table when both factors are powers of two <= 256: two-launch form, no transposes
+    const cf32 *fs_wlo4 = nullptr, *fs_whi4 = nullptr; // four-step form: the same split tables for its twiddle transposition
     const cf32 *fs_wlo = nullptr, *fs_whi = nullptr;   // n = 256 n2 >= 2^16 (fft_tile256_kernel): W_n^j, j < 4096, and W_n^{4096 j}
 };
 constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
