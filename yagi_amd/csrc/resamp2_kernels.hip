@@ -14,14 +14,14 @@
 //                  sample 2u:   yi = D(A,u), yq = F(B,u-1);   sample 2u+1: yi = D(B,u), yq = F(A,u)
 //                  y0 = (yi + yq)/2 scale, y1 = (yi - yq)/2 scale, stored as (y0, y1) pairs
 // Stream indices below zero read the object's state: the two windows (2m samples each, oldest first) kept in HBM.
-// A workgroup stages 256 units of both streams (+ 2m of history) in LDS and every lane walks the 2m taps (wave-uniform:
-// scalar loads); the windows after the block are written by a second, tiny launch.
+// A workgroup stages 1024 units of both streams (+ 2m of history) in LDS and every lane walks the 2m taps (wave-uniform:
+// scalar loads) for its four units, 256 apart; the windows after the block are written by a second, tiny launch.
 #include "devmath.hpp"
 #include "kernels.hpp"
 
 namespace yagi {
 
-constexpr int kR2Tile = 256;
+constexpr int kR2Lanes = 256, kR2Upl = 4, kR2Tile = kR2Lanes * kR2Upl;   // lanes, units per lane, units per workgroup
 
 __device__ __forceinline__ float r2_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ cf32 r2_sub(cf32 a, cf32 b) { return cf32{a.re - b.re, a.im - b.im}; }
@@ -46,7 +46,7 @@ __device__ __forceinline__ T r2_stream(const T *__restrict__ x, size_t nx, int s
 }
 
 template <class T, class C, int MODE>
-__global__ void __launch_bounds__(kR2Tile)
+__global__ void __launch_bounds__(kR2Lanes)
 resamp2_kernel(const T *__restrict__ state, const T *__restrict__ x, size_t nx, const C *__restrict__ h1, int m,
                C scale, int c0, T *__restrict__ y, size_t nunits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char r2_lds[];
@@ -54,7 +54,7 @@ resamp2_kernel(const T *__restrict__ state, const T *__restrict__ x, size_t nx, 
     T *S0 = reinterpret_cast<T *>(r2_lds), *S1 = S0 + span;
     const long long tile0 = (long long)blockIdx.x * kR2Tile;
     // stage both streams: LDS index j <-> stream index tile0 - 2m + j
-    for (int j = threadIdx.x; j < span; j += kR2Tile) {
+    for (int j = threadIdx.x; j < span; j += kR2Lanes) {
         const long long u = tile0 - m2 + j;
         T a, b;
         if (u < 0) {
@@ -68,9 +68,6 @@ resamp2_kernel(const T *__restrict__ state, const T *__restrict__ x, size_t nx, 
         S1[j] = b;
     }
     __syncthreads();
-    const size_t i = (size_t)tile0 + threadIdx.x;
-    if (i >= nunits) return;
-    const int p = m2 + (int)threadIdx.x;                 // LDS index of stream index i
     // F(S, q) with q given as an LDS index: taps oldest first
     auto fir = [&](const T *S, int q) {
         T acc = zero_of<T>();
@@ -78,26 +75,33 @@ resamp2_kernel(const T *__restrict__ state, const T *__restrict__ x, size_t nx, 
         for (int k = 0; k < m2; ++k) acc = mac(acc, w[k], h1[k]);
         return acc;
     };
-    if (MODE == kR2Decim) {
-        y[i] = mul(add(S0[p - m], fir(S1, p)), scale);
-    } else if (MODE == kR2Analyzer) {
-        const T f = fir(S1, p), d = S0[p - m];
-        y[2 * i] = mul(add(f, d), scale);
-        y[2 * i + 1] = mul(r2_sub(f, d), scale);
-    } else if (MODE == kR2Synthesizer || MODE == kR2Interp) {
-        y[2 * i] = mul(S0[p - m], scale);
-        y[2 * i + 1] = mul(fir(S1, p), scale);
-    } else {                                             // filter: unit = a pair of input samples (the last may be half)
-        const T *A = c0 ? S1 : S0, *B = c0 ? S0 : S1;
-        {
-            const T yi = A[p - m], yq = fir(B, p - 1);
-            y[4 * i] = mul(r2_half(add(yi, yq)), scale);
-            y[4 * i + 1] = mul(r2_half(r2_sub(yi, yq)), scale);
-        }
-        if (2 * i + 1 < nx) {
-            const T yi = B[p - m], yq = fir(A, p);
-            y[4 * i + 2] = mul(r2_half(add(yi, yq)), scale);
-            y[4 * i + 3] = mul(r2_half(r2_sub(yi, yq)), scale);
+#pragma unroll
+    for (int uq = 0; uq < kR2Upl; ++uq) {
+        const int lu = (int)threadIdx.x + kR2Lanes * uq;     // unit within the tile
+        const size_t i = (size_t)tile0 + lu;
+        if (i >= nunits) break;
+        const int p = m2 + lu;                               // LDS index of stream index i
+        if (MODE == kR2Decim) {
+            y[i] = mul(add(S0[p - m], fir(S1, p)), scale);
+        } else if (MODE == kR2Analyzer) {
+            const T f = fir(S1, p), d = S0[p - m];
+            y[2 * i] = mul(add(f, d), scale);
+            y[2 * i + 1] = mul(r2_sub(f, d), scale);
+        } else if (MODE == kR2Synthesizer || MODE == kR2Interp) {
+            y[2 * i] = mul(S0[p - m], scale);
+            y[2 * i + 1] = mul(fir(S1, p), scale);
+        } else {                                             // filter: unit = a pair of input samples (the last may be half)
+            const T *A = c0 ? S1 : S0, *B = c0 ? S0 : S1;
+            {
+                const T yi = A[p - m], yq = fir(B, p - 1);
+                y[4 * i] = mul(r2_half(add(yi, yq)), scale);
+                y[4 * i + 1] = mul(r2_half(r2_sub(yi, yq)), scale);
+            }
+            if (2 * i + 1 < nx) {
+                const T yi = B[p - m], yq = fir(A, p);
+                y[4 * i + 2] = mul(r2_half(add(yi, yq)), scale);
+                y[4 * i + 3] = mul(r2_half(r2_sub(yi, yq)), scale);
+            }
         }
     }
 }
@@ -131,7 +135,7 @@ static int launch_resamp2_mode(const T *state, const T *x, size_t nx, const C *h
     const size_t tiles = (nunits + kR2Tile - 1) / kR2Tile;
     if (tiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const size_t lds = 2 * (size_t)(kR2Tile + 2 * m) * sizeof(T);
-    resamp2_kernel<T, C, MODE><<<(unsigned)tiles, kR2Tile, lds, st>>>(state, x, nx, h1, m, scale, c0, y, nunits);
+    resamp2_kernel<T, C, MODE><<<(unsigned)tiles, kR2Lanes, lds, st>>>(state, x, nx, h1, m, scale, c0, y, nunits);
     YG_LAUNCH_CHECK();
     resamp2_state_kernel<T, MODE><<<(4 * m + 255) / 256, 256, 0, st>>>(state, x, nx, m, c0, (long long)n0, (long long)n1,
                                                                         state_next);
