@@ -364,7 +364,7 @@ def main():
         ms2.set_stream(stream.cuda_stream)
         leg("F4_msresamp2_crcf_decim8", lambda: ms2.execute_block_dev(xp, nc // 8, yp), nc, 9,
             f"MsResamp2 decimator by 8 (3 half-band stages, {ms2.get_stage_lengths()}), {nc} input samples; "
-            "algorithmic bytes 8 in + 1 out per input sample (stage intermediates stay in HBM: 8+4+4+2+2+1 actual)")
+            "algorithmic bytes 8 in + 1 out per input sample; one launch, the stage intermediates stay in LDS")
         extras["configs"] = cfg
 
     kernel_name = {1: "firfft_crcf_4096_slide_kernel", 2: "fir_crcf_mfma_kernel<68, true>",

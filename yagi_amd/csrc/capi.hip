@@ -2673,6 +2673,23 @@ struct MsResamp2Obj {
                 cnt *= 2;
                 pp ^= 1;
             }
+        } else if (num_stages <= 4 && fused_decim_fits()) {          // the whole chain in one launch (LDS-resident intermediates)
+            const int ns = (int)num_stages;
+            int mk[4];
+            C sc[4];
+            const C *h1[4];
+            const T *sta[4];
+            T *stn[4];
+            for (int k = 0; k < ns; ++k) {                           // processing order: stage g = S-1-k
+                Resamp2Obj<K> &o = *stage[num_stages - 1 - (size_t)k];
+                mk[k] = o.m;
+                sc[k] = o.scale;
+                h1[k] = o.h1d.template as<C>();
+                sta[k] = o.state[o.cur].template as<T>();
+                stn[k] = o.state[1 - o.cur].template as<T>();
+            }
+            YG_TRY((launch_msresamp2_decim<T, C>(ns, mk, sc, h1, sta, stn, x, y, n, st)));
+            for (size_t g = 0; g < num_stages; ++g) stage[g]->cur = 1 - stage[g]->cur;
         } else {                                                     // stages g = S-1 .. 0, each halves (:177-197)
             size_t cnt = big;
             for (size_t s = 0; s < num_stages; ++s) {
@@ -2686,6 +2703,11 @@ struct MsResamp2Obj {
             }
         }
         return YAGI_OK;
+    }
+    bool fused_decim_fits() const {
+        int mk[4];
+        for (size_t k = 0; k < num_stages && k < 4; ++k) mk[k] = stage[num_stages - 1 - k]->m;
+        return msresamp2_decim_lds((int)num_stages, mk, sizeof(T)) <= 64 * 1024;
     }
     int block_host(const T *x, size_t n, T *y) {
         if (n == 0) return YAGI_OK;

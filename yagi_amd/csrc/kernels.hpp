@@ -115,6 +115,11 @@ int launch_scale_cf32(const cf32 *src, float s, cf32 *dst, size_t n, hipStream_t
 // forms of Resamp2 (resamp2.rs:104-180); values are the `mode` argument of the C ABI
 enum { kR2Filter = 0, kR2Analyzer = 1, kR2Synthesizer = 2, kR2Decim = 3, kR2Interp = 4 };
 constexpr int kR2MaxSemiLen = 1024;
+// MsResamp2 decimator chain in one launch (resamp2_kernels.hip): stages in processing order (full rate first)
+template <class T, class C>
+int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
+                           T *const *state_next, const T *x, T *y, size_t nout, hipStream_t st);
+size_t msresamp2_decim_lds(int ns, const int *m, size_t elem);
 // one block of nx input samples; state = [w0 (2m, oldest first)][w1 (2m)]; state_next receives the windows after the
 // block (must not alias state).  Outputs: filter 2 nx ((y0,y1) pairs), analyzer / synthesizer nx, decim nx/2, interp 2 nx.
 template <class T, class C>

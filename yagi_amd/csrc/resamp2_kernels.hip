@@ -28,6 +28,23 @@ __device__ __forceinline__ cf32 r2_sub(cf32 a, cf32 b) { return cf32{a.re - b.re
 __device__ __forceinline__ float r2_half(float a) { return 0.5f * a; }
 __device__ __forceinline__ cf32 r2_half(cf32 a) { return cf32{0.5f * a.re, 0.5f * a.im}; }
 
+// sum_{k < m2} h1[k] w[k] in tap order (one FMA chain: bit-identical to the per-sample reference loop), the LDS reads of
+// four taps issued together -- with one read per dependent FMA the loop ran at LDS latency (m2 is even and >= 4)
+template <class T, class C>
+__device__ __forceinline__ T r2_branch(const T *__restrict__ w, const C *__restrict__ h1, int m2) {
+    T acc = zero_of<T>();
+    int k = 0;
+    for (; k + 4 <= m2; k += 4) {
+        const T w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+        acc = mac(acc, w0, h1[k]);
+        acc = mac(acc, w1, h1[k + 1]);
+        acc = mac(acc, w2, h1[k + 2]);
+        acc = mac(acc, w3, h1[k + 3]);
+    }
+    for (; k < m2; ++k) acc = mac(acc, w[k], h1[k]);
+    return acc;
+}
+
 // value of stream s (0 / 1) at block-relative index u >= 0
 template <class T, int MODE>
 __device__ __forceinline__ T r2_stream(const T *__restrict__ x, size_t nx, int s, long long u, int c0) {
@@ -69,12 +86,7 @@ resamp2_kernel(const T *__restrict__ state, const T *__restrict__ x, size_t nx, 
     }
     __syncthreads();
     // F(S, q) with q given as an LDS index: taps oldest first
-    auto fir = [&](const T *S, int q) {
-        T acc = zero_of<T>();
-        const T *w = S + (q - (m2 - 1));
-        for (int k = 0; k < m2; ++k) acc = mac(acc, w[k], h1[k]);
-        return acc;
-    };
+    auto fir = [&](const T *S, int q) { return r2_branch<T, C>(S + (q - (m2 - 1)), h1, m2); };
 #pragma unroll
     for (int uq = 0; uq < kR2Upl; ++uq) {
         const int lu = (int)threadIdx.x + kR2Lanes * uq;     // unit within the tile
@@ -156,6 +168,216 @@ int launch_resamp2(int mode, const T *state, const T *x, size_t nx, const C *h1,
     default: return fail(YAGI_ERR_CONFIG, "resamp2: unknown form %d", mode);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// MsResamp2 decimator (msresamp2.rs:177-197), up to four half-band stages in ONE launch: a workgroup produces 256 final
+// outputs; the stages run back to back on polyphase streams kept in LDS (stage k's outputs are written de-interleaved as
+// stage k + 1's S1 / S0 streams), so only the block's input and the final outputs cross HBM -- the chained form moves
+// 8 + 4 + 4 + 2 + 2 + 1 sample-sizes per input sample at three stages, this one 8 + 1.  Every stage evaluates exactly
+// resamp2_kernel's decimator expression (same tap order), so the results are bit-identical to the chain.
+// Stage k (processing order; k = 0 is the full-rate stage) owns outputs [ua_k, ub_k) and reads its streams at pair indices
+// [ua_k - (2 m_k - 1), ub_k); indices below zero come from the stage's two windows (its object's state), which is also how
+// a tile's halo is cut off at the start of the block; inside the block the halo is recomputed from the input.  The
+// workgroup that owns the block's last output writes every stage's windows after the block from its LDS streams.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMsMaxStages = 4, kMsTile = 256;
+template <class T, class C>
+struct MsDecimArgs {
+    int ns;
+    int m[kMsMaxStages];
+    C scale[kMsMaxStages];
+    const C *h1[kMsMaxStages];
+    const T *state[kMsMaxStages];
+    T *state_next[kMsMaxStages];
+};
+
+template <class T, class C, int S>
+__global__ void __launch_bounds__(256)
+msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restrict__ y, size_t nout, int tpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ms_lds[];   // S is a template parameter: every per-stage array below lives in registers
+    constexpr int NP = (1 << (S - 1)) + 1;                       // input pairs per lane and tile: (256 * 2^(S-1) + halo) / 256
+    const long long ntiles = ((long long)nout + kMsTile - 1) / kMsTile;
+    const long long npairs = (long long)nout << (S - 1);         // pairs of the block's input
+    const long long tile0 = (long long)blockIdx.x * tpw;
+    const long long tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+    // output ranges of the stages of a tile, last to first (pair indices; may start below zero near the block's start)
+    long long ua[kMsMaxStages], ub[kMsMaxStages];
+    auto ranges = [&](long long tile) {
+        const long long o0 = tile * kMsTile;
+        long long lo = o0, hi = o0 + kMsTile < (long long)nout ? o0 + kMsTile : (long long)nout;
+#pragma unroll
+        for (int k = S - 1; k >= 0; --k) {
+            ua[k] = lo;
+            ub[k] = hi;
+            lo = 2 * (lo - (2 * a.m[k] - 1));
+            hi = 2 * hi;
+        }
+    };
+    // the input pairs of a tile go through registers: the loads of tile i + 1 are in flight while tile i runs its stages
+    // (a tile is ~20 KiB of input and five short barrier phases: one tile per workgroup left the memory system idle)
+    T qe[NP], qo[NP];
+    const int m20 = 2 * a.m[0];
+    auto issue = [&](long long tile) {                           // clamped: entries below zero are replaced at commit
+        long long lo = tile * kMsTile;
+#pragma unroll
+        for (int k = S - 1; k >= 1; --k) lo = 2 * (lo - (2 * a.m[k] - 1));
+        const long long u0 = lo - (m20 - 1);
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            long long u = u0 + (long long)threadIdx.x + 256 * b;
+            u = u < 0 ? 0 : (u < npairs ? u : npairs - 1);
+            qe[b] = x[2 * u];
+            qo[b] = x[2 * u + 1];
+        }
+    };
+    if (tile0 < tend) issue(tile0);
+    for (long long tile = tile0; tile < tend; ++tile) {
+        ranges(tile);
+        // LDS: per stage two streams S0 / S1 of cnt_k = ub_k - ua_k + 2 m_k - 1 entries (entry j <-> pair index ua_k - (2m_k-1) + j)
+        T *S0[kMsMaxStages], *S1[kMsMaxStages];
+        {
+            T *p = reinterpret_cast<T *>(ms_lds);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const long long cnt = (ub[k] - ua[k]) + 2 * a.m[k] - 1;
+                S0[k] = p;
+                S1[k] = p + cnt;
+                p += 2 * cnt;
+            }
+        }
+        // stage 0's streams from the input (pairs: S1[u] = x[2u], S0[u] = x[2u+1]) or its windows
+        {
+            const long long u0 = ua[0] - (m20 - 1);
+            const int cnt = (int)(ub[0] - u0);
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
+                const int j = (int)threadIdx.x + 256 * b;
+                if (j < cnt) {
+                    const long long u = u0 + j;
+                    T e = qe[b], o = qo[b];
+                    if (u < 0) {
+                        o = a.state[0][m20 + u];
+                        e = a.state[0][m20 + m20 + u];
+                    }
+                    S0[0][j] = o;
+                    S1[0][j] = e;
+                }
+            }
+        }
+        if (tile + 1 < tend) issue(tile + 1);
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            __syncthreads();
+            const int m = a.m[k], m2 = 2 * m;
+            const C *__restrict__ h1 = a.h1[k];
+            const C scale = a.scale[k];
+            const long long u0 = ua[k] - (m2 - 1);                   // pair index of stream entry 0
+            const bool last = k + 1 == S;
+            // the next stage's streams below index zero: its windows
+            long long v0 = 0;
+            const int kn = k + 1 < S ? k + 1 : k;                    // next stage (unused when `last`; constant once unrolled)
+            if (!last) {
+                const int m2n = 2 * a.m[kn];
+                v0 = ua[kn] - (m2n - 1);                              // pair index of the next stage's entry 0
+                if (v0 < 0) {
+                    const int nneg = (int)(-v0 < ub[kn] - v0 ? -v0 : ub[kn] - v0);
+                    for (int j = threadIdx.x; j < nneg; j += 256) {
+                        const long long v = v0 + j;
+                        S0[kn][j] = a.state[kn][m2n + v];
+                        S1[kn][j] = a.state[kn][m2n + m2n + v];
+                    }
+                }
+            }
+            const long long first = ua[k] > 0 ? ua[k] : 0;
+            const int nout_k = (int)(ub[k] - first);
+            const int p0 = (int)(first - u0);                        // stream entry of the first output's pair index
+            const int q0 = (int)(first - 2 * v0);                    // first output as a sample of the next stage's input, from its entry 0
+            for (int j = threadIdx.x; j < nout_k; j += 256) {
+                const int p = p0 + j;
+                const T acc = r2_branch<T, C>(S1[k] + (p - (m2 - 1)), h1, m2);
+                const T out = mul(add(S0[k][p - m], acc), scale);
+                if (last) y[first + j] = out;
+                else {
+                    const int q = q0 + j;                             // sample index: pair q >> 1, odd -> S0, even -> S1
+                    ((q & 1) ? S0[kn] : S1[kn])[q >> 1] = out;
+                }
+            }
+        }
+        // the windows after the block: last 2m pairs of every stage's streams (the tile that holds the block's end)
+        if ((size_t)ub[S - 1] == nout) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int m2 = 2 * a.m[k];
+                const long long u0 = ua[k] - (m2 - 1);
+                for (int j = threadIdx.x; j < m2; j += 256) {
+                    const long long u = ub[k] - m2 + j;               // >= u0: the tile holds at least one output
+                    a.state_next[k][j] = S0[k][u - u0];
+                    a.state_next[k][m2 + j] = S1[k][u - u0];
+                }
+            }
+        }
+        __syncthreads();                                             // the next tile overwrites the streams
+    }
+}
+
+template <class T, class C>
+int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
+                           T *const *state_next, const T *x, T *y, size_t nout, hipStream_t st) {
+    if (ns < 1 || ns > kMsMaxStages) return fail(YAGI_ERR_INTERNAL, "msresamp2: %d stages in one launch", ns);
+    if (nout == 0) return YAGI_OK;
+    MsDecimArgs<T, C> a;
+    a.ns = ns;
+    size_t lds = 0;
+    for (int k = 0; k < ns; ++k) {
+        a.m[k] = m[k];
+        a.scale[k] = scale[k];
+        a.h1[k] = h1[k];
+        a.state[k] = state[k];
+        a.state_next[k] = state_next[k];
+    }
+    {   // the widest tile: ranges of an interior workgroup
+        long long lo = 0, hi = kMsTile;
+        for (int k = ns - 1; k >= 0; --k) {
+            lds += 2 * (size_t)((hi - lo) + 2 * m[k] - 1) * sizeof(T);
+            lo = 2 * (lo - (2 * m[k] - 1));
+            hi = 2 * hi;
+        }
+    }
+    if (lds > 64 * 1024) return fail(YAGI_ERR_INTERNAL, "msresamp2: the fused chain needs %zu bytes of LDS", lds);
+    const size_t tiles = (nout + kMsTile - 1) / kMsTile;
+    // consecutive tiles per workgroup (input prefetch across tiles) while >= ~4096 workgroups remain
+    int tpw = 1;
+    while (tpw < 8 && tiles / (size_t)(2 * tpw) >= 4096) tpw *= 2;
+    const size_t nblk = (tiles + tpw - 1) / tpw;
+    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    switch (ns) {
+    case 1: msresamp2_decim_kernel<T, C, 1><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
+    case 2: msresamp2_decim_kernel<T, C, 2><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
+    case 3: msresamp2_decim_kernel<T, C, 3><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
+    default: msresamp2_decim_kernel<T, C, 4><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
+    }
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+// LDS the fused chain would need (host-side dispatch test)
+size_t msresamp2_decim_lds(int ns, const int *m, size_t elem) {
+    size_t lds = 0;
+    long long lo = 0, hi = kMsTile;
+    for (int k = ns - 1; k >= 0; --k) {
+        lds += 2 * (size_t)((hi - lo) + 2 * m[k] - 1) * elem;
+        lo = 2 * (lo - (2 * m[k] - 1));
+        hi = 2 * hi;
+    }
+    return lds;
+}
+
+template int launch_msresamp2_decim<float, float>(int, const int *, const float *, const float *const *, const float *const *,
+                                                  float *const *, const float *, float *, size_t, hipStream_t);
+template int launch_msresamp2_decim<cf32, float>(int, const int *, const float *, const float *const *, const cf32 *const *,
+                                                 cf32 *const *, const cf32 *, cf32 *, size_t, hipStream_t);
+template int launch_msresamp2_decim<cf32, cf32>(int, const int *, const cf32 *, const cf32 *const *, const cf32 *const *,
+                                                cf32 *const *, const cf32 *, cf32 *, size_t, hipStream_t);
 
 template int launch_resamp2<float, float>(int, const float *, const float *, size_t, const float *, int, float, int,
                                           float *, float *, hipStream_t);
