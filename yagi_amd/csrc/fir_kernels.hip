@@ -720,8 +720,18 @@ rresamp_kernel(const typename K::T *__restrict__ win, const typename K::T *__res
         const int nq = n * Q, i = nq / P, br = nq - i * P;
         const C *hrow = hb + (size_t)br * Ls;
         const T *xp = xs + (Ls - 1) + bl * Q + i;
+        // one FMA chain in tap order (bit-identical to the per-sample loop), the reads of four taps issued together
         T acc = zero_of<T>();
-        for (int k = 0; k < Ls; ++k) acc = mac(acc, xp[-k], hrow[k]);
+        int k = 0;
+        for (; k + 4 <= Ls; k += 4) {
+            const T x0 = xp[-k], x1 = xp[-k - 1], x2 = xp[-k - 2], x3 = xp[-k - 3];
+            const C h0 = hrow[k], h1 = hrow[k + 1], h2 = hrow[k + 2], h3 = hrow[k + 3];
+            acc = mac(acc, x0, h0);
+            acc = mac(acc, x1, h1);
+            acc = mac(acc, x2, h2);
+            acc = mac(acc, x3, h3);
+        }
+        for (; k < Ls; ++k) acc = mac(acc, xp[-k], hrow[k]);
         y[b0 * P + o] = mul(acc, scale);
     }
 }
