@@ -177,6 +177,40 @@ def test_msresamp2_vs_oracle(ya, oracle, kind, interp):
         assert got.shape == want.shape and rel_l2(got, want) <= 3e-6, (kind, interp, ns)
 
 
+@pytest.mark.parametrize("kind,ms", [("crcf", [10, 5, 3]), ("rrrf", [6, 4]), ("cccf", [4, 3, 3, 2])])
+def test_msresamp2_fused_decimator_equals_the_chain_on_a_large_block(ya, oracle, kind, ms):
+    """the decimator chain in one launch (<= 4 stages, LDS-resident intermediates, several tiles per workgroup from
+    8192 tiles on) against the same stages run one after the other as Resamp2 objects: identical bits, over two calls
+    (the windows of every stage written by the fused kernel's last workgroup carry into the second call)"""
+    ns = len(ms)
+    rate = 1 << ns
+    hfs = [oracle.halfband_kaiser(m, 60.0) for m in ms]
+    q = ya.MsResamp2.from_taps(kind, ya.MsResamp2.DECIM, ms, hfs)
+    chain = [ya.Resamp2(kind, hfs[g], ms[g]) for g in range(ns)]
+    chain[0].set_scale(1.0 / rate)                             # zeta multiplies the last stage's output (msresamp2.rs:197)
+    cplx = kind != "rrrf"
+    dt = np.complex64 if cplx else np.float32
+    n1, n2 = (1 << 21) + 1000, 4099                            # outputs of the two calls: 8196 tiles, then a short block
+    x = ya.gen_complex_dev(SEED + 21, (n1 + n2) * rate)          # rrrf reads the first half of it as real samples
+    got = ya.DeviceArray(n1 + n2, dt)
+    item = np.dtype(dt).itemsize
+    q.execute_block_dev(x.ptr, n1, got.ptr)
+    q.execute_block_dev(x.ptr + n1 * rate * item, n2, got.ptr + n1 * item)
+    # the chain: stage g = S-1 first, each halves
+    outs = []
+    for off, cnt in ((0, n1), (n1, n2)):
+        src, n = x.ptr + off * rate * item, cnt * rate
+        for g in range(ns - 1, -1, -1):
+            dst = ya.DeviceArray(n // 2, dt)
+            chain[g].execute_block_dev(ya.Resamp2.DECIM, src, n, dst)
+            keep = dst                                          # keep the buffer alive while the next stage reads it
+            src, n = dst.ptr, n // 2
+            outs.append(keep)
+        ya.synchronize()
+        want = keep.to_numpy()
+        assert np.array_equal(got.to_numpy(cnt, off), want), (kind, off)
+
+
 def test_msresamp2_config_copy(ya, oracle):                                     # :38-48, :300-337
     for bad in [lambda: ya.MsResamp2("crcf", 1, 17, 0.4, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.5, 0.0, 60.0),
                 lambda: ya.MsResamp2("crcf", 1, 2, 0.0, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.4, 0.1, 60.0)]:
