@@ -145,6 +145,21 @@ __device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff
     const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
 }
+template <class T>
+__device__ __forceinline__ T buf_ld_t(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 4) {
+        const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        T v;
+        __builtin_memcpy(&v, &q, 4);
+        return v;
+    } else {
+        static_assert(sizeof(T) == 8, "4- or 8-byte samples");
+        const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        T v;
+        __builtin_memcpy(&v, &q, 8);
+        return v;
+    }
+}
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
     v2u_t q;
     q.x = __float_as_uint(v.x);

@@ -373,6 +373,34 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
     int jj = (int)threadIdx.x / M, ph = (int)threadIdx.x - jj * M;
     // eight loads per lane in flight before the LDS writes; (jj, ph) advance with the stores, in order
     const bool inside = base >= 0 && base + total <= xlen;       // block-uniform: every entry lies inside x
+    // Interior tile, M a power of two with NT / M a multiple of R: the lane's decimation phase is fixed
+    // (ph = tid mod M) and its row index advances by NT / M per trip, so the LDS slot advances by a constant and the
+    // samples come through a buffer descriptor (one VGPR offset, the trip in an SGPR; entries past `total` read zero):
+    // no address arithmetic per entry -- the generic staging below spent as many vector instructions as the taps.
+    const int lgM = 31 - __builtin_clz((unsigned)M);
+    const bool fast = inside && (M & (M - 1)) == 0 && M <= NT && ((NT >> lgM) & (R - 1)) == 0 &&
+                      (unsigned long long)total * sizeof(T) < 0xffffffffull;
+    if (fast) {
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + base, (unsigned)((size_t)total * sizeof(T)));
+        const unsigned vo = (unsigned)sizeof(T) * threadIdx.x;
+        const int rows = NT >> lgM;                              // row entries per trip
+        const int sstride = rows + (rows >> LG);
+        const int jj0 = (int)threadIdx.x >> lgM;
+        T *dst = xs + ((int)threadIdx.x & (M - 1)) * pitch + jj0 + (jj0 >> LG);
+        for (int t0 = 0; t0 * NT < total; t0 += 8) {
+            T r[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) r[it] = buf_ld_t<T>(rx, vo, (unsigned)sizeof(T) * NT * (unsigned)(t0 + it));
+            if ((t0 + 8) * NT <= total) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) dst[sstride * (t0 + it)] = r[it];
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    if ((int)threadIdx.x + NT * (t0 + it) < total) dst[sstride * (t0 + it)] = r[it];
+            }
+        }
+    } else
     for (int e0 = threadIdx.x; e0 < total; e0 += 8 * NT) {
         T r[8];
 #pragma unroll
