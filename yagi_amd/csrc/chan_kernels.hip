@@ -554,11 +554,14 @@ firpfbch_syn_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
 // column i) takes its 8 values back, pushes them through its p-deep register ring and stores y[f M + i] coalesced.
 // A run starts with W = 8 (p <= 8) or 16 warm-up frames (the p-1 frames before it, inverse-transformed again)
 // whose outputs are not stored.
-template <int P, int LGM>
+// FAST: all runs of the workgroup are full: channel frames and outputs go through buffer descriptors (one VGPR offset per
+// lane, frame steps in SGPRs), no range checks; only workgroup 0's warm-up frames take the history path.  A partial last
+// workgroup is a launch of its own with FAST = false (wg0 = its index).
+template <int P, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                         const float *__restrict__ h, const float2 *__restrict__ twM,
-                        float2 *__restrict__ y, size_t nframes, int run) {
+                        float2 *__restrict__ y, size_t nframes, int run, unsigned wg0) {
     constexpr int M = 1 << LGM, lgM = LGM;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -576,9 +579,15 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
     for (int n = 0; n < P; ++n) hc[n] = h[c + n * M];
     const int hist_len = (P - 1) * M;
     const long long x_len = (long long)nframes * M;
-    const long long f_begin = ((long long)blockIdx.x * G + g) * run;
+    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long f_begin = wg_first + (long long)g * run;
     const long long left = (long long)nframes - f_begin;
     const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
+    const bool first_wg = blockIdx.x + wg0 == 0;                 // its warm-up frames come from the history
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(FAST && !first_wg ? x + (wg_first - W) * M : x, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(FAST ? y + wg_first * M : y, 0xffffffffu);
+    const unsigned vx = 8u * ((unsigned)(g * run) * M + c);
+    const unsigned sx0 = first_wg ? 0u : 8u * ((unsigned)W << lgM);             // descriptor offset of frame t = 0
     float2 w[P];
 #pragma unroll
     for (int n = 0; n < P; ++n) w[n] = make_float2(0.f, 0.f);
@@ -587,9 +596,13 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
         // channel frames t .. t+7 of this group (negative: the frames before the run; beyond the end: zeros)
 #pragma unroll
         for (int j = 0; j < kColHalf; ++j) {
-            const long long f = f_begin + t + j;
-            va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, f * M + c, x_len)
-                                                                 : make_float2(0.f, 0.f);
+            if (FAST && (t >= 0 || !first_wg)) {                 // uniform: only workgroup 0's warm-up needs the history
+                va[(g * kColHalf + j) * pitch + c] = buf_ld(rx, vx, sx0 + 8u * (unsigned)((t + j) << lgM));
+            } else {
+                const long long f = f_begin + t + j;
+                va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, f * M + c, x_len)
+                                                                     : make_float2(0.f, 0.f);
+            }
         }
         __syncthreads();
         stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
@@ -610,7 +623,9 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
                 acc.x = fmaf(sv.x, hc[n], acc.x);
                 acc.y = fmaf(sv.y, hc[n], acc.y);
             }
-            if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc;
+            if constexpr (FAST) {
+                if (t >= 0) buf_st(ry, vx, 8u * ((unsigned)(t + j) << lgM), acc);       // t: uniform, a multiple of 8
+            } else if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc;
         }
         __syncthreads();                             // the next half tile overwrites va / vb
     };
@@ -637,11 +652,20 @@ static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float 
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
-    firpfbch_syn_col_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
-                                                                     reinterpret_cast<const float2 *>(x), h,
-                                                                     reinterpret_cast<const float2 *>(twM),
-                                                                     reinterpret_cast<float2 *>(y), nframes, (int)run);
-    YG_LAUNCH_CHECK();
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    // a partial last workgroup takes the checked kernel
+    const size_t nfull = nframes / ((size_t)G * run);
+    if (nfull) {
+        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
+        YG_LAUNCH_CHECK();
+    }
+    if (nfull < nblk) {
+        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
+                                                                                         (unsigned)nfull);
+        YG_LAUNCH_CHECK();
+    }
     return YAGI_OK;
 }
 
@@ -1265,11 +1289,11 @@ firpfbch2_syn_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 // its half (b = i + f M/2 = c) -- with the taps of lag k: hk[k] = h[i + (k & 1) M/2 + (k >> 1) M] (lag 2n: first sum, lag
 // 2n + 1: second sum; added in lag order like the tiled kernel).  For M >= 128 a wave is all-lower or all-upper half:
 // the two halves of a workgroup alternate, nobody diverges.  A run starts with W = 8 (m = 2) or 16 warm-up steps.
-template <int P2, int LGM>
+template <int P2, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                          const float *__restrict__ h, const float2 *__restrict__ twM,
-                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run) {
+                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run, unsigned wg0) {
     constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1288,10 +1312,17 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
     for (int k = 0; k < P2; ++k) hk[k] = 0.5f * h[i + (k & 1) * M2 + (k >> 1) * M];
     const int hist_len = (P2 - 1) * M;
     const long long x_len = (long long)nsteps * M;
-    const long long s_begin = ((long long)blockIdx.x * G + g) * run;
+    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long s_begin = wg_first + (long long)g * run;
     const long long left = (long long)nsteps - s_begin;
     const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
     const int par = (int)((step0 + (unsigned long long)s_begin) & 1ull) ^ hi;   // this lane's outputs: steps t with (t + par) even
+    // FAST (as in firpfbch_syn_col_kernel): buffer descriptors, no history or range checks
+    const bool first_wg = blockIdx.x + wg0 == 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(FAST && !first_wg ? x + (wg_first - W) * M : x, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(FAST ? y + wg_first * M2 : y, 0xffffffffu);
+    const unsigned vx = 8u * ((unsigned)(g * run) * M + c), vy = 8u * ((unsigned)(g * run) * M2 + i);
+    const unsigned sx0 = first_wg ? 0u : 8u * ((unsigned)W << lgM);
     float2 w[P2];
 #pragma unroll
     for (int n = 0; n < P2; ++n) w[n] = make_float2(0.f, 0.f);
@@ -1299,9 +1330,13 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
         constexpr int S0 = decltype(slot0)::value;
 #pragma unroll
         for (int j = 0; j < kColHalf; ++j) {
-            const long long s = s_begin + t + j;
-            va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, s * M + c, x_len)
-                                                                 : make_float2(0.f, 0.f);
+            if (FAST && (t >= 0 || !first_wg)) {
+                va[(g * kColHalf + j) * pitch + c] = buf_ld(rx, vx, sx0 + 8u * (unsigned)((t + j) << lgM));
+            } else {
+                const long long s = s_begin + t + j;
+                va[(g * kColHalf + j) * pitch + c] = (t + j < nvalid) ? load_hist(hist, hist_len, x, s * M + c, x_len)
+                                                                     : make_float2(0.f, 0.f);
+            }
         }
         __syncthreads();
         stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
@@ -1315,7 +1350,7 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
 #pragma unroll
         for (int j = 0; j < kColHalf; ++j) {
             w[(S0 + j) % P2] = res[(g * kColHalf + j) * pitch + c];
-            if (((j + par) & 1) == 0 && t + j >= 0 && t + j < nvalid) {      // t is even: parity of the step = parity of j
+            if (((j + par) & 1) == 0 && t + j >= 0 && (FAST || t + j < nvalid)) {   // t is even: parity of the step = parity of j
                 float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < P2; ++k) {
@@ -1323,7 +1358,8 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
                     acc.x = fmaf(sv.x, hk[k], acc.x);
                     acc.y = fmaf(sv.y, hk[k], acc.y);
                 }
-                y[(s_begin + t + j) * M2 + i] = acc;
+                if constexpr (FAST) buf_st(ry, vy, 8u * ((unsigned)(t + j) << (lgM - 1)), acc);
+                else y[(s_begin + t + j) * M2 + i] = acc;
             }
         }
         __syncthreads();                             // the next half tile overwrites va / vb
@@ -1351,10 +1387,21 @@ static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
-    firpfbch2_syn_col_kernel<P2, LGM><<<(unsigned)nblk, 256, lds, st>>>(
-        reinterpret_cast<const float2 *>(hist), reinterpret_cast<const float2 *>(x), h,
-        reinterpret_cast<const float2 *>(twM), (unsigned long long)step0, reinterpret_cast<float2 *>(y), nsteps, (int)run);
-    YG_LAUNCH_CHECK();
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    const unsigned long long s0 = (unsigned long long)step0;
+    // a partial last workgroup takes the checked kernel
+    const size_t nfull = nsteps / ((size_t)G * run);
+    if (nfull) {
+        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
+        YG_LAUNCH_CHECK();
+    }
+    if (nfull < nblk) {
+        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps,
+                                                                                           (int)run, (unsigned)nfull);
+        YG_LAUNCH_CHECK();
+    }
     return YAGI_OK;
 }
 
