@@ -187,8 +187,7 @@ constexpr int kColHalf = 8;
 
 // M = 2^LGM is a template parameter so that only the two radix passes M needs are instantiated (with a run-time
 // plan the register allocation is that of the widest radix: 200 VGPRs).
-// FULL: every workgroup of the launch holds G * run frames (the tail, if any, is a second launch of one workgroup with
-// FULL = false and wg0 = its index; hist_next goes to the last launch only).
+// FULL: every workgroup of the launch holds G * run frames (otherwise the whole launch takes FULL = false).
 template <int P, int LGM, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
@@ -314,18 +313,16 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    // workgroups that hold G * run frames take the check-free kernel; a partial last workgroup is a launch of its own
-    const size_t nfull = nframes / ((size_t)G * run);
+    // every workgroup holds G * run frames (block lengths that are multiples of G * run: the streaming case): the
+    // check-free kernel; otherwise the checked kernel for the whole launch (a launch of its own for the partial tail would
+    // run one workgroup's whole run alone on the device)
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
-    if (nfull)
-        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
-                                                                            nfull == nblk ? fn : nullptr, 0u);
-    YG_LAUNCH_CHECK();
-    if (nfull < nblk)
-        firpfbch_col_kernel<P, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
-                                                                                      fn, (unsigned)nfull);
+    if (nframes % ((size_t)G * run) == 0)
+        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, 0u);
+    else
+        firpfbch_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, 0u);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -555,8 +552,8 @@ firpfbch_syn_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
 // A run starts with W = 8 (p <= 8) or 16 warm-up frames (the p-1 frames before it, inverse-transformed again)
 // whose outputs are not stored.
 // FAST: all runs of the workgroup are full: channel frames and outputs go through buffer descriptors (one VGPR offset per
-// lane, frame steps in SGPRs), no range checks; only workgroup 0's warm-up frames take the history path.  A partial last
-// workgroup is a launch of its own with FAST = false (wg0 = its index).
+// lane, frame steps in SGPRs), no range checks; only workgroup 0's warm-up frames take the history path.  A launch with a
+// partial last workgroup takes FAST = false as a whole.
 template <int P, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
@@ -655,17 +652,11 @@ static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float 
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
-    // a partial last workgroup takes the checked kernel
-    const size_t nfull = nframes / ((size_t)G * run);
-    if (nfull) {
-        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
-        YG_LAUNCH_CHECK();
-    }
-    if (nfull < nblk) {
-        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run,
-                                                                                         (unsigned)nfull);
-        YG_LAUNCH_CHECK();
-    }
+    if (nframes % ((size_t)G * run) == 0)            // every workgroup full (see launch_firpfbch_col)
+        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
+    else
+        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
+    YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
@@ -825,7 +816,7 @@ __device__ unsigned long long g_chan_stamps[2048 * 4 * 12];
 // residue class, then a run-time planned M/R-point transform), otherwise two static radix passes.
 // FULL: every workgroup of the launch holds G * run steps -- samples and outputs go through buffer descriptors (one
 // VGPR byte offset per lane, the steps in SGPRs / immediates: no 64-bit address arithmetic, no per-step checks); a
-// partial last workgroup is a launch of its own with FULL = false and wg0 = its index.
+// launch with a partial last workgroup takes FULL = false as a whole.
 template <int P, int LGM, bool SHARDED, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
@@ -1001,29 +992,16 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
-    // workgroups that hold G * run steps take the check-free kernel; a partial last workgroup is a launch of its own
-    const size_t nfull = nsteps / ((size_t)G * run);
+    // every workgroup full: the check-free kernel; otherwise the checked kernel for the whole launch (see launch_firpfbch_col)
+    const bool full = nsteps % ((size_t)G * run) == 0;
     const Pow2Plan plan = nranks > 1 ? make_pow2_plan(M / nranks) : Pow2Plan{0, {0}};
     const int rk = nranks > 1 ? rank : 0, nr = nranks > 1 ? nranks : 1;
-    if (nfull) {
-        float2 *f1 = nfull == nblk ? fn : nullptr;
-        if (nranks > 1)
-            firpfbch2_col_kernel<P, LGM, true, true><<<(unsigned)nfull, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy,
-                                                                                      nsteps, (int)run, f1, 0u);
-        else
-            firpfbch2_col_kernel<P, LGM, false, true><<<(unsigned)nfull, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy,
-                                                                                       nsteps, (int)run, f1, 0u);
-        YG_LAUNCH_CHECK();
-    }
-    if (nfull < nblk) {
-        if (nranks > 1)
-            firpfbch2_col_kernel<P, LGM, true, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(
-                fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, (unsigned)nfull);
-        else
-            firpfbch2_col_kernel<P, LGM, false, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(
-                fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, (unsigned)nfull);
-        YG_LAUNCH_CHECK();
-    }
+    const unsigned grid = (unsigned)nblk;
+#define YG_C5_LAUNCH(SH, FU) firpfbch2_col_kernel<P, LGM, SH, FU><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, 0u)
+    if (nranks > 1) { if (full) YG_C5_LAUNCH(true, true); else YG_C5_LAUNCH(true, false); }
+    else { if (full) YG_C5_LAUNCH(false, true); else YG_C5_LAUNCH(false, false); }
+#undef YG_C5_LAUNCH
+    YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
@@ -1391,17 +1369,11 @@ static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
     const unsigned long long s0 = (unsigned long long)step0;
-    // a partial last workgroup takes the checked kernel
-    const size_t nfull = nsteps / ((size_t)G * run);
-    if (nfull) {
-        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nfull, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
-        YG_LAUNCH_CHECK();
-    }
-    if (nfull < nblk) {
-        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)(nblk - nfull), 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps,
-                                                                                           (int)run, (unsigned)nfull);
-        YG_LAUNCH_CHECK();
-    }
+    if (nsteps % ((size_t)G * run) == 0)             // every workgroup full (see launch_firpfbch_col)
+        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
+    else
+        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
+    YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
 
