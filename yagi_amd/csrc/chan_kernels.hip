@@ -883,22 +883,21 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 #pragma unroll
         for (int kk = 0; kk < kPairs; ++kk) {
             const float2 old = w[(S0 + kk) % P];
-            // even step: the early-fed half already sees the new sample, the late-fed half the old one
-            w[(S0 + kk) % P] = bpar ? old : xin[kk];
-            float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+            // even step: the early-fed half already sees the new sample, the late-fed half the old one; odd step:
+            // everybody is fed.  The two chains differ in the newest slot only; they advance together as one 4-wide
+            // FMA per lag (two packed FMAs on different accumulators: a dependent packed FMA directly behind its producer
+            // costs a wait state), each still adding its taps in lag order.
+            typedef float v4f_t __attribute__((ext_vector_type(4)));
+            const float2 new0 = bpar ? old : xin[kk];
+            w[(S0 + kk) % P] = xin[kk];
+            v4f_t a01 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < P; ++m) {
-                const float2 sv = w[(S0 + kk - m + 4 * P) % P];
-                a0.x = fmaf(sv.x, h0r[m], a0.x);
-                a0.y = fmaf(sv.y, h0r[m], a0.y);
+                const float2 s1 = w[(S0 + kk - m + 4 * P) % P];
+                const float2 s0 = m == 0 ? new0 : s1;
+                a01 = __builtin_elementwise_fma(v4f_t{s0.x, s0.y, s1.x, s1.y}, v4f_t{h0r[m], h0r[m], h1[m], h1[m]}, a01);
             }
-            w[(S0 + kk) % P] = xin[kk];                                   // odd step: everybody is fed
-#pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const float2 sv = w[(S0 + kk - m + 4 * P) % P];
-                a1.x = fmaf(sv.x, h1[m], a1.x);
-                a1.y = fmaf(sv.y, h1[m], a1.y);
-            }
+            const float2 a0 = make_float2(a01.x, a01.y), a1 = make_float2(a01.z, a01.w);
             va[(g * kColHalf + 2 * kk) * pitch + b] = a0;
             va[(g * kColHalf + 2 * kk + 1) * pitch + b] = a1;
         }
