@@ -610,19 +610,49 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
             __syncthreads();
             res = va;
         }
+        // two frames at a time as one 4-wide FMA per lag (a dependent packed FMA directly behind its producer costs a
+        // wait state); frame j's oldest sample shares its ring slot with frame j + 1's newest, so it is kept aside; every
+        // frame still adds its taps in lag order
+        // (P = 16: the paired form needs 129-154 VGPRs, 3 waves per SIMD: one frame at a time)
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        if constexpr (P > 8) {
 #pragma unroll
-        for (int j = 0; j < kColHalf; ++j) {
+            for (int j = 0; j < kColHalf; ++j) {
+                w[(S0 + j) % P] = res[(g * kColHalf + j) * pitch + c];
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < P; ++n) {
+                    const float2 sv = w[(S0 + j - n + 4 * P) % P];
+                    acc.x = fmaf(sv.x, hc[n], acc.x);
+                    acc.y = fmaf(sv.y, hc[n], acc.y);
+                }
+                if constexpr (FAST) {
+                    if (t >= 0) buf_st(ry, vx, 8u * ((unsigned)(t + j) << lgM), acc);   // t: uniform, a multiple of 8
+                } else if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc;
+            }
+        } else
+#pragma unroll
+        for (int j = 0; j < kColHalf; j += 2) {
             w[(S0 + j) % P] = res[(g * kColHalf + j) * pitch + c];
-            float2 acc = make_float2(0.f, 0.f);
+            const float2 oldest = w[(S0 + j + 1) % P];           // lag P - 1 of frame j
+            w[(S0 + j + 1) % P] = res[(g * kColHalf + j + 1) * pitch + c];
+            v4f_t a2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int n = 0; n < P; ++n) {
-                const float2 sv = w[(S0 + j - n + 4 * P) % P];
-                acc.x = fmaf(sv.x, hc[n], acc.x);
-                acc.y = fmaf(sv.y, hc[n], acc.y);
+                const float2 s0 = n == P - 1 ? oldest : w[(S0 + j - n + 4 * P) % P];
+                const float2 s1 = w[(S0 + j + 1 - n + 4 * P) % P];
+                a2 = __builtin_elementwise_fma(v4f_t{s0.x, s0.y, s1.x, s1.y}, v4f_t{hc[n], hc[n], hc[n], hc[n]}, a2);
             }
+            const float2 acc0 = make_float2(a2.x, a2.y), acc1 = make_float2(a2.z, a2.w);
             if constexpr (FAST) {
-                if (t >= 0) buf_st(ry, vx, 8u * ((unsigned)(t + j) << lgM), acc);       // t: uniform, a multiple of 8
-            } else if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc;
+                if (t >= 0) {                                    // t: uniform, a multiple of 8
+                    buf_st(ry, vx, 8u * ((unsigned)(t + j) << lgM), acc0);
+                    buf_st(ry, vx, 8u * ((unsigned)(t + j + 1) << lgM), acc1);
+                }
+            } else {
+                if (t + j >= 0 && t + j < nvalid) y[(f_begin + t + j) * M + c] = acc0;
+                if (t + j + 1 >= 0 && t + j + 1 < nvalid) y[(f_begin + t + j + 1) * M + c] = acc1;
+            }
         }
         __syncthreads();                             // the next half tile overwrites va / vb
     };
