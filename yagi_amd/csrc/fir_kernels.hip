@@ -375,7 +375,7 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
     const bool inside = base >= 0 && base + total <= xlen;       // block-uniform: every entry lies inside x
     // Interior tile, M a power of two with NT / M a multiple of R: the lane's decimation phase is fixed
     // (ph = tid mod M) and its row index advances by NT / M per trip, so the LDS slot advances by a constant and the
-    // samples come through a buffer descriptor (one VGPR offset, the trip in an SGPR; entries past `total` read zero):
+    // samples come through a buffer descriptor of exactly `total` entries (entries past it are range-checked away, never read):
     // no address arithmetic per entry -- the generic staging below spent as many vector instructions as the taps.
     const int lgM = 31 - __builtin_clz((unsigned)M);
     const bool fast = inside && (M & (M - 1)) == 0 && M <= NT && ((NT >> lgM) & (R - 1)) == 0 &&
@@ -390,7 +390,8 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
         for (int t0 = 0; t0 * NT < total; t0 += 8) {
             T r[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) r[it] = buf_ld_t<T>(rx, vo, (unsigned)sizeof(T) * NT * (unsigned)(t0 + it));
+            for (int it = 0; it < 8; ++it)       // the trip goes into the VGPR offset: that is the part the range check covers
+                r[it] = buf_ld_t<T>(rx, vo + (unsigned)sizeof(T) * NT * (unsigned)(t0 + it), 0u);
             if ((t0 + 8) * NT <= total) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) dst[sstride * (t0 + it)] = r[it];
