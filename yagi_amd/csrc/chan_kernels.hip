@@ -192,7 +192,7 @@ template <int P, int LGM, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                     const float *__restrict__ h, const float2 *__restrict__ twM,
-                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next, unsigned wg0) {
+                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next) {
     constexpr int M = 1 << LGM, lgM = LGM;
     chan_write_next_hist(hist, (P - 1) * M, x, nframes * (size_t)M, hist_next);
     // 8, 16: one pass; 32 = 8 x 4, 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
@@ -213,7 +213,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     const long long x_len = (long long)nframes * M;
     // one workgroup = G consecutive runs of `run` frames (no grid-stride loop); all frame indices below are
     // 32-bit offsets from the workgroup's first frame
-    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long wg_first = (long long)blockIdx.x * G * run;
     const long long wg_left = (long long)nframes - wg_first;                     // > 0
     const int wg_frames = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
     auto group_frames = [&](int gq) {                // frames of group gq that exist
@@ -320,9 +320,9 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
     if (nframes % ((size_t)G * run) == 0)
-        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, 0u);
+        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn);
     else
-        firpfbch_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, 0u);
+        firpfbch_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -558,7 +558,7 @@ template <int P, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                         const float *__restrict__ h, const float2 *__restrict__ twM,
-                        float2 *__restrict__ y, size_t nframes, int run, unsigned wg0) {
+                        float2 *__restrict__ y, size_t nframes, int run) {
     constexpr int M = 1 << LGM, lgM = LGM;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -576,11 +576,11 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
     for (int n = 0; n < P; ++n) hc[n] = h[c + n * M];
     const int hist_len = (P - 1) * M;
     const long long x_len = (long long)nframes * M;
-    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long wg_first = (long long)blockIdx.x * G * run;
     const long long f_begin = wg_first + (long long)g * run;
     const long long left = (long long)nframes - f_begin;
     const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
-    const bool first_wg = blockIdx.x + wg0 == 0;                 // its warm-up frames come from the history
+    const bool first_wg = blockIdx.x == 0;                 // its warm-up frames come from the history
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(FAST && !first_wg ? x + (wg_first - W) * M : x, 0xffffffffu);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(FAST ? y + wg_first * M : y, 0xffffffffu);
     const unsigned vx = 8u * ((unsigned)(g * run) * M + c);
@@ -683,9 +683,9 @@ static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float 
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
     if (nframes % ((size_t)G * run) == 0)            // every workgroup full (see launch_firpfbch_col)
-        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
+        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
     else
-        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, 0u);
+        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM, Pow2Plan plan,
                      int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */,
-                     float2 *__restrict__ hist_next, unsigned wg0) {
+                     float2 *__restrict__ hist_next) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
     chan_write_next_hist(hist, hist_len, x, nsteps * (size_t)M2, hist_next);
@@ -879,7 +879,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     const float invM = 1.0f / (float)M;
     const long long x_len = (long long)nsteps * M2;
     // one workgroup = G consecutive runs of `run` steps; step indices below are 32-bit offsets from its first
-    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long wg_first = (long long)blockIdx.x * G * run;
     const long long wg_left = (long long)nsteps - wg_first;
     const int wg_steps = (int)(wg_left < (long long)G * run ? wg_left : (long long)G * run);
     auto group_steps = [&](int gq) {
@@ -1026,7 +1026,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const Pow2Plan plan = nranks > 1 ? make_pow2_plan(M / nranks) : Pow2Plan{0, {0}};
     const int rk = nranks > 1 ? rank : 0, nr = nranks > 1 ? nranks : 1;
     const unsigned grid = (unsigned)nblk;
-#define YG_C5_LAUNCH(SH, FU) firpfbch2_col_kernel<P, LGM, SH, FU><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, 0u)
+#define YG_C5_LAUNCH(SH, FU) firpfbch2_col_kernel<P, LGM, SH, FU><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn)
     if (nranks > 1) { if (full) YG_C5_LAUNCH(true, true); else YG_C5_LAUNCH(true, false); }
     else { if (full) YG_C5_LAUNCH(false, true); else YG_C5_LAUNCH(false, false); }
 #undef YG_C5_LAUNCH
@@ -1300,7 +1300,7 @@ template <int P2, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                          const float *__restrict__ h, const float2 *__restrict__ twM,
-                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run, unsigned wg0) {
+                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run) {
     constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1319,13 +1319,13 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
     for (int k = 0; k < P2; ++k) hk[k] = 0.5f * h[i + (k & 1) * M2 + (k >> 1) * M];
     const int hist_len = (P2 - 1) * M;
     const long long x_len = (long long)nsteps * M;
-    const long long wg_first = (long long)(blockIdx.x + wg0) * G * run;
+    const long long wg_first = (long long)blockIdx.x * G * run;
     const long long s_begin = wg_first + (long long)g * run;
     const long long left = (long long)nsteps - s_begin;
     const int nvalid = (int)(left < 0 ? 0 : (left < run ? left : run));
     const int par = (int)((step0 + (unsigned long long)s_begin) & 1ull) ^ hi;   // this lane's outputs: steps t with (t + par) even
     // FAST (as in firpfbch_syn_col_kernel): buffer descriptors, no history or range checks
-    const bool first_wg = blockIdx.x + wg0 == 0;
+    const bool first_wg = blockIdx.x == 0;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(FAST && !first_wg ? x + (wg_first - W) * M : x, 0xffffffffu);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(FAST ? y + wg_first * M2 : y, 0xffffffffu);
     const unsigned vx = 8u * ((unsigned)(g * run) * M + c), vy = 8u * ((unsigned)(g * run) * M2 + i);
@@ -1399,9 +1399,9 @@ static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float
     float2 *fy = reinterpret_cast<float2 *>(y);
     const unsigned long long s0 = (unsigned long long)step0;
     if (nsteps % ((size_t)G * run) == 0)             // every workgroup full (see launch_firpfbch_col)
-        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
+        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run);
     else
-        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, 0u);
+        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
