@@ -326,7 +326,7 @@ def test_firdecim_random_vs_f64(ya, oracle, kind, M, L, n):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("M,L", [(2, 2), (2, 9), (2, 65), (3, 64), (3, 100), (4, 65), (4, 129), (5, 7), (7, 50), (8, 129),
-                                 (8, 257), (8, 2049), (12, 200), (12, 400), (16, 33), (16, 513)])
+                                 (8, 257), (8, 2049), (12, 200), (12, 400), (16, 33), (16, 513), (32, 513), (64, 1025)])
 def test_firdecim_register_window_kernel(ya, oracle, kind, M, L):
     """Blocks of >= 512 outputs with >= 8 taps per decimation phase take the per-phase register-window kernel
     (8- or 4-sample window, workgroups of 256 / 128 / 64 lanes by phase length and what fits the LDS;
