@@ -333,7 +333,7 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
 // the two transform buffers stay at 32 KiB each; three static radix passes (512 = 8x8x8, 1024 = 16x8x8).
 // The generic tiled kernel re-reads every sample (tile + p - 1)/tile times and got 0.4-0.8 TB/s on these shapes.
 // ---------------------------------------------------------------------------------------------
-template <int P, int LGM>
+template <int P, int LGM, bool FULL>                // FULL: every workgroup of the launch holds `run` frames (see firpfbch_col_kernel)
 __global__ void __launch_bounds__(256)
 firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM,
@@ -359,8 +359,9 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
     const long long f_begin = (long long)blockIdx.x * run;
     const long long left = (long long)nframes - f_begin;
     const int nvalid = (int)(left < run ? left : run);
-    const bool full = nvalid == run;
     const float2 *xg = x + f_begin * M + t;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + f_begin * M, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + f_begin * M, 0xffffffffu);
     float2 w[C][P];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc)
@@ -373,7 +374,8 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
         for (int j = 0; j < HF; ++j)
 #pragma unroll
             for (int cc = 0; cc < C; ++cc)
-                d[cc][j] = (full || f + j < nvalid) ? xg[((unsigned)(f + j) << lgM) + 256u * cc] : make_float2(0.f, 0.f);
+                if constexpr (FULL) d[cc][j] = buf_ld(rx, 8u * (t + 256u * cc), 8u * ((unsigned)(f + j) << lgM));
+                else d[cc][j] = (f + j < nvalid) ? xg[((unsigned)(f + j) << lgM) + 256u * cc] : make_float2(0.f, 0.f);
     };
     float2 *yb = y + f_begin * M;
     auto half_tile = [&](float2 (&xin)[C][HF], int f, auto slot0) {
@@ -404,7 +406,8 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
         for (int i = 0; i < HF * C; ++i) {
             const int e = t + 256 * i;
             const int q = e >> lgM, k = e & (M - 1);
-            if (full || f + q < nvalid) yb[((unsigned)(f + q) << lgM) + k] = vb[q * pitch + k];
+            if constexpr (FULL) buf_st(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)f << lgM), vb[q * pitch + k]);
+            else if (f + q < nvalid) yb[((unsigned)(f + q) << lgM) + k] = vb[q * pitch + k];
         }
         __syncthreads();
     };
@@ -429,14 +432,19 @@ static int launch_firpfbch_wide(const cf32 *hist, const cf32 *x, const float *h,
     const size_t lds = (2 * (size_t)HF * (M + 32 / HF) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_wide_kernel<P, LGM>),
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_wide_kernel<P, LGM, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch_wide_kernel<P, LGM, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    firpfbch_wide_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(reinterpret_cast<const float2 *>(hist),
-                                                                  reinterpret_cast<const float2 *>(x), h,
-                                                                  reinterpret_cast<const float2 *>(twM),
-                                                                  reinterpret_cast<float2 *>(y), nframes, (int)run);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (nframes % run == 0)
+        firpfbch_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
+    else
+        firpfbch_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -1036,7 +1044,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
 
 // firpfbch2, column-sliding form for wide banks (M = 512, 1024; 2m in {2, 4}): every lane owns M/256 windows
 // b = t + 256 cc (so the early/late-fed split b >= M/2 is uniform per cc), half tiles of HS = 4096/M steps.
-template <int P, int LGM>
+template <int P, int LGM, bool FULL>                // FULL: every workgroup of the launch holds `run` steps (see firpfbch_col_kernel)
 __global__ void __launch_bounds__(256)
 firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                       const float *__restrict__ h, const float2 *__restrict__ twM,
@@ -1072,7 +1080,8 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
     const long long s_begin = (long long)blockIdx.x * run;       // even
     const long long left = (long long)nsteps - s_begin;
     const int nvalid = (int)(left < run ? left : run);
-    const bool full = nvalid == run;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + s_begin * M2, 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + s_begin * M, 0xffffffffu);
     float2 w[C][P];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
@@ -1088,8 +1097,12 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
             const int bpar = (2 * cc >= C) ? 1 : 0;
             const float2 *xg = x + (s_begin + bpar) * M2 + pos[cc];          // + 2kk*M2 = kk*M
 #pragma unroll
-            for (int kk = 0; kk < HP; ++kk)
-                d[cc][kk] = (full || st + 2 * kk + bpar < nvalid) ? xg[(unsigned)(st / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+            for (int kk = 0; kk < HP; ++kk) {
+                if constexpr (FULL)
+                    d[cc][kk] = buf_ld(rx, 8u * (unsigned)(bpar * M2 + pos[cc]), 8u * ((unsigned)(st / 2 + kk) << lgM));
+                else
+                    d[cc][kk] = (st + 2 * kk + bpar < nvalid) ? xg[(unsigned)(st / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+            }
         }
     };
     float2 *yb = y + s_begin * M;
@@ -1132,7 +1145,10 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
         for (int i = 0; i < HS * C; ++i) {
             const int e = t + 256 * i;
             const int q = e >> lgM, k = e & (M - 1);
-            if (full || st + q < nvalid) {
+            if constexpr (FULL) {
+                const float2 v = vb[q * pitch + k];
+                buf_st(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)st << lgM), make_float2(v.x * invM, v.y * invM));
+            } else if (st + q < nvalid) {
                 const float2 v = vb[q * pitch + k];
                 yb[((unsigned)(st + q) << lgM) + k] = make_float2(v.x * invM, v.y * invM);
             }
@@ -1160,13 +1176,19 @@ static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, 
     const size_t lds = (2 * (size_t)HS * (M + 32 / HS) + (size_t)M) * sizeof(float2);
     static bool raised = false;
     if (!raised) {
-        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_wide_kernel<P, LGM>),
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_wide_kernel<P, LGM, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(firpfbch2_wide_kernel<P, LGM, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    firpfbch2_wide_kernel<P, LGM><<<(unsigned)nblk, 256, lds, st>>>(
-        reinterpret_cast<const float2 *>(hist), hist_len, reinterpret_cast<const float2 *>(x), h,
-        reinterpret_cast<const float2 *>(twM), reinterpret_cast<float2 *>(y), nsteps, (int)run);
+    const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
+    const float2 *ftw = reinterpret_cast<const float2 *>(twM);
+    float2 *fy = reinterpret_cast<float2 *>(y);
+    if (nsteps % run == 0)
+        firpfbch2_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run);
+    else
+        firpfbch2_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
