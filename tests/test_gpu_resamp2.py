@@ -211,6 +211,28 @@ def test_msresamp2_fused_decimator_equals_the_chain_on_a_large_block(ya, oracle,
         assert np.array_equal(got.to_numpy(cnt, off), want), (kind, off)
 
 
+def test_msresamp2_fused_decimator_randomised(ya, oracle):
+    """seeded sweep: 1-4 stages, semi-lengths 2..14, three calls of ragged lengths each (1 output .. a few tiles); the
+    one-launch chain equals the Resamp2 stages run one after the other bit for bit, state carried from call to call"""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        kind = ("rrrf", "crcf", "cccf")[case % 3]
+        ns = int(rng.integers(1, 5))
+        ms = [int(v) for v in rng.integers(2, 15, ns)]
+        rate = 1 << ns
+        hfs = [oracle.halfband_kaiser(m, 60.0) for m in ms]
+        q = ya.MsResamp2.from_taps(kind, ya.MsResamp2.DECIM, ms, hfs)
+        chain = [ya.Resamp2(kind, hfs[g], ms[g]) for g in range(ns)]
+        chain[0].set_scale(1.0 / rate)
+        for n in (int(rng.integers(1, 40)), int(rng.integers(200, 1500)), int(rng.integers(1, 700))):
+            x = rand_samples(rng, kind, n * rate)
+            got = q.execute_block(x)
+            cur = x
+            for g in range(ns - 1, -1, -1):
+                cur = chain[g].execute_block(ya.Resamp2.DECIM, cur)
+            assert np.array_equal(got, cur), (case, kind, ms, n)
+
+
 def test_msresamp2_config_copy(ya, oracle):                                     # :38-48, :300-337
     for bad in [lambda: ya.MsResamp2("crcf", 1, 17, 0.4, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.5, 0.0, 60.0),
                 lambda: ya.MsResamp2("crcf", 1, 2, 0.0, 0.0, 60.0), lambda: ya.MsResamp2("crcf", 1, 2, 0.4, 0.1, 60.0)]:
