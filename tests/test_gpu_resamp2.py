@@ -211,25 +211,32 @@ def test_msresamp2_fused_decimator_equals_the_chain_on_a_large_block(ya, oracle,
         assert np.array_equal(got.to_numpy(cnt, off), want), (kind, off)
 
 
-def test_msresamp2_fused_decimator_randomised(ya, oracle):
-    """seeded sweep: 1-4 stages, semi-lengths 2..14, three calls of ragged lengths each (1 output .. a few tiles); the
-    one-launch chain equals the Resamp2 stages run one after the other bit for bit, state carried from call to call"""
-    rng = np.random.default_rng(2024)
+@pytest.mark.parametrize("interp", [False, True])
+def test_msresamp2_fused_chain_randomised(ya, oracle, interp):
+    """seeded sweep: 1-4 stages, semi-lengths 2..14, three calls of ragged lengths each (1 sample .. a few tiles); the
+    one-launch decimator / interpolator chain equals the Resamp2 stages run one after the other bit for bit, state
+    carried from call to call"""
+    rng = np.random.default_rng(2024 + int(interp))
     for case in range(24):
         kind = ("rrrf", "crcf", "cccf")[case % 3]
         ns = int(rng.integers(1, 5))
         ms = [int(v) for v in rng.integers(2, 15, ns)]
         rate = 1 << ns
         hfs = [oracle.halfband_kaiser(m, 60.0) for m in ms]
-        q = ya.MsResamp2.from_taps(kind, ya.MsResamp2.DECIM, ms, hfs)
+        q = ya.MsResamp2.from_taps(kind, ya.MsResamp2.INTERP if interp else ya.MsResamp2.DECIM, ms, hfs)
         chain = [ya.Resamp2(kind, hfs[g], ms[g]) for g in range(ns)]
-        chain[0].set_scale(1.0 / rate)
+        if not interp:
+            chain[0].set_scale(1.0 / rate)
         for n in (int(rng.integers(1, 40)), int(rng.integers(200, 1500)), int(rng.integers(1, 700))):
-            x = rand_samples(rng, kind, n * rate)
+            x = rand_samples(rng, kind, n if interp else n * rate)
             got = q.execute_block(x)
             cur = x
-            for g in range(ns - 1, -1, -1):
-                cur = chain[g].execute_block(ya.Resamp2.DECIM, cur)
+            if interp:
+                for g in range(ns):
+                    cur = chain[g].execute_block(ya.Resamp2.INTERP, cur)
+            else:
+                for g in range(ns - 1, -1, -1):
+                    cur = chain[g].execute_block(ya.Resamp2.DECIM, cur)
             assert np.array_equal(got, cur), (case, kind, ms, n)
 
 

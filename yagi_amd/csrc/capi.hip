@@ -2663,7 +2663,24 @@ struct MsResamp2Obj {
         }
         const T *src = x;
         int pp = 0;
-        if (interp) {                                                // stage s doubles n 2^s samples (:154-175)
+        if (interp && num_stages <= 4 && fused_interp_fits()) {      // the whole chain in one launch (LDS-resident levels)
+            const int ns = (int)num_stages;
+            int mk[4];
+            C sc[4];
+            const C *h1[4];
+            const T *sta[4];
+            T *stn[4];
+            for (int k = 0; k < ns; ++k) {                           // processing order: stage k
+                Resamp2Obj<K> &o = *stage[(size_t)k];
+                mk[k] = o.m;
+                sc[k] = o.scale;
+                h1[k] = o.h1d.template as<C>();
+                sta[k] = o.state[o.cur].template as<T>();
+                stn[k] = o.state[1 - o.cur].template as<T>();
+            }
+            YG_TRY((launch_msresamp2_interp<T, C>(ns, mk, sc, h1, sta, stn, x, y, n, st)));
+            for (size_t g = 0; g < num_stages; ++g) stage[g]->cur = 1 - stage[g]->cur;
+        } else if (interp) {                                         // stage s doubles n 2^s samples (:154-175)
             size_t cnt = n;
             for (size_t s = 0; s < num_stages; ++s) {
                 const bool last = s + 1 == num_stages;
@@ -2703,6 +2720,11 @@ struct MsResamp2Obj {
             }
         }
         return YAGI_OK;
+    }
+    bool fused_interp_fits() const {
+        int mk[4];
+        for (size_t k = 0; k < num_stages && k < 4; ++k) mk[k] = stage[k]->m;
+        return msresamp2_interp_lds((int)num_stages, mk, sizeof(T)) <= 64 * 1024;
     }
     bool fused_decim_fits() const {
         int mk[4];

@@ -120,6 +120,11 @@ template <class T, class C>
 int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
                            T *const *state_next, const T *x, T *y, size_t nout, hipStream_t st);
 size_t msresamp2_decim_lds(int ns, const int *m, size_t elem);
+// MsResamp2 interpolator chain in one launch: stages in processing order (input rate first)
+template <class T, class C>
+int launch_msresamp2_interp(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
+                            T *const *state_next, const T *x, T *y, size_t nin, hipStream_t st);
+size_t msresamp2_interp_lds(int ns, const int *m, size_t elem);
 // one block of nx input samples; state = [w0 (2m, oldest first)][w1 (2m)]; state_next receives the windows after the
 // block (must not alias state).  Outputs: filter 2 nx ((y0,y1) pairs), analyzer / synthesizer nx, decim nx/2, interp 2 nx.
 template <class T, class C>

@@ -255,9 +255,10 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
                 if (j < cnt) {
                     const long long u = u0 + j;
                     T e = qe[b], o = qo[b];
-                    if (u < 0) {
-                        o = a.state[0][m20 + u];
-                        e = a.state[0][m20 + m20 + u];
+                    if (u < 0) {                                 // a halo reaches further back than the stage's windows
+                        const bool held = u >= -m20;             // near the block's start: those entries are never used
+                        o = held ? a.state[0][m20 + u] : zero_of<T>();
+                        e = held ? a.state[0][m20 + m20 + u] : zero_of<T>();
                     }
                     S0[0][j] = o;
                     S1[0][j] = e;
@@ -283,8 +284,9 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
                     const int nneg = (int)(-v0 < ub[kn] - v0 ? -v0 : ub[kn] - v0);
                     for (int j = threadIdx.x; j < nneg; j += 256) {
                         const long long v = v0 + j;
-                        S0[kn][j] = a.state[kn][m2n + v];
-                        S1[kn][j] = a.state[kn][m2n + m2n + v];
+                        const bool held = v >= -m2n;                  // see the stage-0 fill
+                        S0[kn][j] = held ? a.state[kn][m2n + v] : zero_of<T>();
+                        S1[kn][j] = held ? a.state[kn][m2n + m2n + v] : zero_of<T>();
                     }
                 }
             }
@@ -360,6 +362,167 @@ int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const 
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// MsResamp2 interpolator (msresamp2.rs:154-175), up to four half-band stages in ONE launch: the mirror image of
+// msresamp2_decim_kernel.  Level 0 is the block's input, stage k turns level k into level k + 1 (twice as long) with
+// exactly resamp2_kernel's interpolator expression (y[2i] = S0[i - m] scale, y[2i+1] = scale sum_j h1[j] S1[i - (2m-1) + j];
+// both streams carry the level's samples, below index zero the stage's two windows); the levels stay in LDS, the last
+// stage stores to y.  A workgroup owns 256 input samples; a level's halo is recomputed from the level below, the
+// workgroup that holds the block's end writes every stage's windows.  Bit-identical to the chain of Resamp2 stages.
+// ---------------------------------------------------------------------------------------------
+template <class T, class C, int S>
+__global__ void __launch_bounds__(256)
+msresamp2_interp_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restrict__ y, size_t nin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ms_lds[];
+    // lo[k], hi[k]: range of level k this tile holds (level 0 = input); level S = the tile's outputs
+    long long lo[kMsMaxStages + 1], hi[kMsMaxStages + 1];
+    {
+        const long long i0 = (long long)blockIdx.x * kMsTile;
+        const long long i1 = i0 + kMsTile < (long long)nin ? i0 + kMsTile : (long long)nin;
+        lo[S] = i0 << S;
+        hi[S] = i1 << S;
+#pragma unroll
+        for (int k = S - 1; k >= 0; --k) {
+            // stage k makes outputs [lo[k+1], hi[k+1]) (both even) from units [lo[k+1]/2, hi[k+1]/2): level-k samples from
+            // (2 m_k - 1) before the first unit; stage k - 1 produces pairs, so the range is widened to even bounds
+            long long l = (lo[k + 1] >> 1) - (2 * a.m[k] - 1), h = hi[k + 1] >> 1;
+            if (k > 0) { l &= ~1ll; h = (h + 1) & ~1ll; }
+            lo[k] = l;
+            hi[k] = h;
+        }
+    }
+    T *S0[kMsMaxStages], *S1[kMsMaxStages];                      // level k's two streams, entry j <-> index lo[k] + j
+    {
+        T *p = reinterpret_cast<T *>(ms_lds);
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const long long cnt = hi[k] - lo[k];
+            S0[k] = p;
+            S1[k] = p + cnt;
+            p += 2 * cnt;
+        }
+    }
+    // fill of a level's entries below index zero (the stage's windows) and, for level 0, the input itself
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int m2 = 2 * a.m[k];
+        const int cnt = (int)(hi[k] - lo[k]);
+        if (k == 0) {
+            for (int j = threadIdx.x; j < cnt; j += 256) {
+                const long long u = lo[0] + j;
+                T v0, v1;
+                if (u < 0) {                                     // a halo reaches further back than the stage's windows near
+                    const bool held = u >= -m2;                  // the block's start: those entries are never used
+                    v0 = held ? a.state[0][m2 + u] : zero_of<T>();
+                    v1 = held ? a.state[0][m2 + m2 + u] : zero_of<T>();
+                } else {
+                    v0 = v1 = (u < (long long)nin) ? x[u] : zero_of<T>();
+                }
+                S0[0][j] = v0;
+                S1[0][j] = v1;
+            }
+        } else if (lo[k] < 0) {
+            const int nneg = (int)(-lo[k] < cnt ? -lo[k] : cnt);
+            for (int j = threadIdx.x; j < nneg; j += 256) {
+                const long long u = lo[k] + j;
+                const bool held = u >= -m2;
+                S0[k][j] = held ? a.state[k][m2 + u] : zero_of<T>();
+                S1[k][j] = held ? a.state[k][m2 + m2 + u] : zero_of<T>();
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        __syncthreads();
+        const int m = a.m[k], m2 = 2 * m;
+        const C *__restrict__ h1 = a.h1[k];
+        const C scale = a.scale[k];
+        const bool last = k + 1 == S;
+        const int kn = k + 1 < S ? k + 1 : k;
+        // units whose outputs the next level needs and that exist (index >= 0): [u_lo, u_hi)
+        const long long first = (lo[k + 1] >> 1) > 0 ? (lo[k + 1] >> 1) : 0;
+        const int nun = (int)((hi[k + 1] >> 1) - first);
+        const int p0 = (int)(first - lo[k]);                         // entry of the first unit in level k's streams
+        const int q0 = last ? 0 : (int)(2 * first - lo[kn]);         // entry of its first output in level k + 1
+        for (int j = threadIdx.x; j < nun; j += 256) {
+            const int p = p0 + j;
+            const T acc = r2_branch<T, C>(S1[k] + (p - (m2 - 1)), h1, m2);
+            const T e = mul(S0[k][p - m], scale), o = mul(acc, scale);
+            if (last) {
+                y[2 * (first + j)] = e;
+                y[2 * (first + j) + 1] = o;
+            } else {
+                const int q = q0 + 2 * j;
+                S0[kn][q] = e; S0[kn][q + 1] = o;
+                S1[kn][q] = e; S1[kn][q + 1] = o;
+            }
+        }
+    }
+    // the windows after the block (both windows of a stage have seen the same samples since the block began; below index
+    // zero they still hold what they held): the workgroup with the block's last input
+    if ((size_t)(hi[S] >> S) == nin) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int m2 = 2 * a.m[k];
+            const long long end = (long long)nin << k;               // samples of level k in the block
+            for (int j = threadIdx.x; j < m2; j += 256) {
+                const long long u = end - m2 + j;                    // >= lo[k]
+                a.state_next[k][j] = S0[k][u - lo[k]];
+                a.state_next[k][m2 + j] = S1[k][u - lo[k]];
+            }
+        }
+    }
+}
+
+static size_t msresamp2_interp_lds_impl(int ns, const int *m, size_t elem) {
+    long long lo = 0, hi = (long long)kMsTile << ns;
+    size_t lds = 0;
+    for (int k = ns - 1; k >= 0; --k) {
+        long long l = (lo >> 1) - (2 * m[k] - 1), h = hi >> 1;
+        if (k > 0) { l &= ~1ll; h = (h + 1) & ~1ll; }
+        lds += 2 * (size_t)(h - l) * elem;
+        lo = l;
+        hi = h;
+    }
+    return lds;
+}
+size_t msresamp2_interp_lds(int ns, const int *m, size_t elem) { return msresamp2_interp_lds_impl(ns, m, elem); }
+
+template <class T, class C>
+int launch_msresamp2_interp(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
+                            T *const *state_next, const T *x, T *y, size_t nin, hipStream_t st) {
+    if (ns < 1 || ns > kMsMaxStages) return fail(YAGI_ERR_INTERNAL, "msresamp2: %d stages in one launch", ns);
+    if (nin == 0) return YAGI_OK;
+    MsDecimArgs<T, C> a;
+    a.ns = ns;
+    for (int k = 0; k < ns; ++k) {
+        a.m[k] = m[k];
+        a.scale[k] = scale[k];
+        a.h1[k] = h1[k];
+        a.state[k] = state[k];
+        a.state_next[k] = state_next[k];
+    }
+    const size_t lds = msresamp2_interp_lds_impl(ns, m, sizeof(T));
+    if (lds > 64 * 1024) return fail(YAGI_ERR_INTERNAL, "msresamp2: the fused chain needs %zu bytes of LDS", lds);
+    const size_t tiles = (nin + kMsTile - 1) / kMsTile;
+    if (tiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    switch (ns) {
+    case 1: msresamp2_interp_kernel<T, C, 1><<<(unsigned)tiles, 256, lds, st>>>(a, x, y, nin); break;
+    case 2: msresamp2_interp_kernel<T, C, 2><<<(unsigned)tiles, 256, lds, st>>>(a, x, y, nin); break;
+    case 3: msresamp2_interp_kernel<T, C, 3><<<(unsigned)tiles, 256, lds, st>>>(a, x, y, nin); break;
+    default: msresamp2_interp_kernel<T, C, 4><<<(unsigned)tiles, 256, lds, st>>>(a, x, y, nin); break;
+    }
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+template int launch_msresamp2_interp<float, float>(int, const int *, const float *, const float *const *, const float *const *,
+                                                   float *const *, const float *, float *, size_t, hipStream_t);
+template int launch_msresamp2_interp<cf32, float>(int, const int *, const float *, const float *const *, const cf32 *const *,
+                                                  cf32 *const *, const cf32 *, cf32 *, size_t, hipStream_t);
+template int launch_msresamp2_interp<cf32, cf32>(int, const int *, const cf32 *, const cf32 *const *, const cf32 *const *,
+                                                 cf32 *const *, const cf32 *, cf32 *, size_t, hipStream_t);
+
 // LDS the fused chain would need (host-side dispatch test)
 size_t msresamp2_decim_lds(int ns, const int *m, size_t elem) {
     size_t lds = 0;
