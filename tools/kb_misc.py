@@ -24,6 +24,10 @@ rr = ya.Rresamp.new_kaiser("crcf", 3, 5, 15, -1.0, 60.0)
 cases["rresamp_crcf 3/5 m=15"] = (lambda: rr.execute_block_dev(x, n // 5, y), 8 * n + 8 * (n // 5) * 3)
 fi = ya.FirInterpolationFilter.new_kaiser("crcf", 4, 8, 60.0)
 cases["firinterp_crcf x4 m=8"] = (lambda: fi.execute_block_dev(x, n // 4, y), 8 * (n // 4) + 8 * n)
+md = ya.MsResamp2("crcf", ya.MsResamp2.DECIM, 3, 0.45, 0.0, 60.0)
+cases["msresamp2_crcf decim /8 (3 stages)"] = (lambda: md.execute_block_dev(x, n // 8, y), 8 * n + n)
+mi = ya.MsResamp2("crcf", ya.MsResamp2.INTERP, 3, 0.45, 0.0, 60.0)
+cases["msresamp2_crcf interp x8 (3 stages), n/8 in"] = (lambda: mi.execute_block_dev(x, n // 8, y), n + 8 * n)
 for k, (fn, nbytes) in cases.items():
     for _ in range(30):
         fn()
