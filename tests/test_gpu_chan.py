@@ -34,10 +34,12 @@ def test_firpfbch_vs_oracle(ya, oracle, M, m):
 
 @pytest.mark.parametrize("M,m,nfr", [(64, 8, 4099), (64, 2, 1000), (128, 4, 777), (256, 8, 300), (256, 2, 64), (64, 4, 65),
                                      (512, 4, 333), (512, 2, 64), (1024, 2, 200), (1024, 4, 77), (512, 4, 20000),
-                                     (8, 2, 5001), (16, 4, 3000), (32, 8, 2077), (8, 8, 70000)])
+                                     (8, 2, 5001), (16, 4, 3000), (32, 8, 2077), (8, 8, 70000),
+                                     (64, 3, 1000), (256, 5, 300), (16, 1, 2000), (128, 6, 500), (32, 7, 640)])
 def test_firpfbch_column_kernel_long_runs(ya, oracle, M, m, nfr):
     """the column-sliding kernels (M in {64,128,256}, p in {4,8,16}; wide banks M in {512,1024}, p in {4,8}): ragged
-    frame counts, carried state; 20000 frames of 512 channels run several tiles per workgroup"""
+    frame counts, carried state; 20000 frames of 512 channels run several tiles per workgroup; branch lengths between the
+    built sizes (p = 2, 6, 10, 12, 14) run on the next one with zero taps"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 0.5 / M, 60.0)
     x = oracle.gen_complex(SEED + 4, nfr * M)
     want = oracle.FirPfbCh(M, 2 * m, h).analyzer_execute(x)
@@ -94,7 +96,8 @@ def test_firpfbch2_vs_oracle(ya, oracle, M, m):
 
 @pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200), (64, 8, 700),
                                     (128, 8, 130), (512, 2, 333), (512, 1, 64), (512, 4, 90), (1024, 1, 200), (1024, 2, 77),
-                                    (512, 2, 20000), (8, 2, 5000), (16, 1, 3001), (32, 4, 2000), (8, 4, 70000)])
+                                    (512, 2, 20000), (8, 2, 5000), (16, 1, 3001), (32, 4, 2000), (8, 4, 70000),
+                                    (64, 3, 1000), (256, 5, 300), (128, 6, 500), (32, 7, 640), (256, 3, 2048)])
 def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
     """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8,16}, even first step) incl. ragged tails"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)
@@ -306,7 +309,8 @@ def test_config_c5_firpfbch2_256ch_full_size(ya, oracle):
 
 
 @pytest.mark.parametrize("M,m,nfr", [(4, 2, 50), (8, 4, 333), (64, 8, 200), (6, 3, 77), (10, 2, 100), (256, 4, 65), (1, 3, 20),
-                                     (512, 2, 40), (48, 4, 90), (64, 8, 5000), (16, 2, 9001), (256, 2, 40000), (32, 4, 777)])
+                                     (512, 2, 40), (48, 4, 90), (64, 8, 5000), (16, 2, 9001), (256, 2, 40000), (32, 4, 777),
+                                     (64, 3, 1000), (256, 5, 300), (16, 1, 2000), (128, 7, 500)])
 def test_firpfbch_synthesizer_vs_oracle(ya, oracle, M, m, nfr):
     """synthesizer (PARITY UNPINNED like the analyzer): frames of channel samples -> time samples, against
     the frame-by-frame restatement; state carried across calls; its state is independent of the analyzer's"""
@@ -372,7 +376,8 @@ def test_firpfbch_analysis_synthesis_round_trip(ya, M, p):
 
 
 @pytest.mark.parametrize("M,m,ns", [(4, 1, 40), (8, 2, 101), (16, 4, 64), (64, 3, 50), (6, 2, 33), (10, 1, 50), (256, 2, 21),
-                                    (8, 2, 300), (16, 4, 257), (32, 2, 211), (64, 4, 230), (128, 2, 200), (256, 4, 215)])
+                                    (8, 2, 300), (16, 4, 257), (32, 2, 211), (64, 4, 230), (128, 2, 200), (256, 4, 215),
+                                    (64, 3, 300), (256, 3, 215), (16, 1, 400), (128, 1, 257)])
 def test_firpfbch2_synthesizer_vs_oracle(ya, oracle, M, m, ns):
     """firpfbch2 synthesizer (PARITY UNPINNED) against the step-by-step restatement; odd splits carry the
     step parity and the window across calls; independent of the analyzer's state.  Calls of >= 64 steps with M a power

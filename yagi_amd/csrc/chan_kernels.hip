@@ -192,9 +192,10 @@ template <int P, int LGM, bool FULL>
 __global__ void __launch_bounds__(256)
 firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                     const float *__restrict__ h, const float2 *__restrict__ twM,
-                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next) {
+                    float2 *__restrict__ y, size_t nframes, int run, float2 *__restrict__ hist_next,
+                    int p_real /* taps per branch, <= P: the rest are zero */) {
     constexpr int M = 1 << LGM, lgM = LGM;
-    chan_write_next_hist(hist, (P - 1) * M, x, nframes * (size_t)M, hist_next);
+    chan_write_next_hist(hist, (p_real - 1) * M, x, nframes * (size_t)M, hist_next);
     // 8, 16: one pass; 32 = 8 x 4, 64 = 8 x 8, 128 = 16 x 8, 256 = 16 x 16
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -208,8 +209,8 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     float hc[P];
 #pragma unroll
-    for (int n = 0; n < P; ++n) hc[n] = h[(M - 1 - c) + n * M];
-    const int hist_len = (P - 1) * M;
+    for (int n = 0; n < P; ++n) hc[n] = n < p_real ? h[(M - 1 - c) + n * M] : 0.0f;   // branch lengths between the built sizes: zero-padded
+    const int hist_len = (p_real - 1) * M;
     const long long x_len = (long long)nframes * M;
     // one workgroup = G consecutive runs of `run` frames (no grid-stride loop); all frame indices below are
     // 32-bit offsets from the workgroup's first frame
@@ -292,7 +293,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
 
 template <int P, int LGM>
 static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
-                               cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next) {
+                               cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
@@ -320,9 +321,9 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);
     if (nframes % ((size_t)G * run) == 0)
-        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn);
+        firpfbch_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, p_real);
     else
-        firpfbch_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn);
+        firpfbch_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, fn, p_real);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -467,13 +468,14 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
 #define YG_COL_CASE(PP)                                                                              \
     case PP:                                                                                         \
         if (hist_written) *hist_written = hist_next != nullptr;                                      \
-        return M == 8 ? launch_firpfbch_col<PP, 3>(hist, x, h, twM, y, nframes, st, hist_next)                  \
-             : M == 16 ? launch_firpfbch_col<PP, 4>(hist, x, h, twM, y, nframes, st, hist_next)                 \
-             : M == 32 ? launch_firpfbch_col<PP, 5>(hist, x, h, twM, y, nframes, st, hist_next)                 \
-             : M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st, hist_next)                 \
-             : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st, hist_next)                \
-                        : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st, hist_next);
-        switch (p) {
+        return M == 8 ? launch_firpfbch_col<PP, 3>(hist, x, h, twM, y, nframes, st, hist_next, p)                  \
+             : M == 16 ? launch_firpfbch_col<PP, 4>(hist, x, h, twM, y, nframes, st, hist_next, p)                 \
+             : M == 32 ? launch_firpfbch_col<PP, 5>(hist, x, h, twM, y, nframes, st, hist_next, p)                 \
+             : M == 64 ? launch_firpfbch_col<PP, 6>(hist, x, h, twM, y, nframes, st, hist_next, p)                 \
+             : M == 128 ? launch_firpfbch_col<PP, 7>(hist, x, h, twM, y, nframes, st, hist_next, p)                \
+                        : launch_firpfbch_col<PP, 8>(hist, x, h, twM, y, nframes, st, hist_next, p);
+        // branch lengths between the built sizes take the next one with zero taps behind theirs
+        switch (p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : 0) {
             YG_COL_CASE(4)
             YG_COL_CASE(8)
             YG_COL_CASE(16)
@@ -566,7 +568,7 @@ template <int P, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                         const float *__restrict__ h, const float2 *__restrict__ twM,
-                        float2 *__restrict__ y, size_t nframes, int run) {
+                        float2 *__restrict__ y, size_t nframes, int run, int p_real /* <= P: the other taps are zero */) {
     constexpr int M = 1 << LGM, lgM = LGM;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -581,8 +583,8 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     float hc[P];
 #pragma unroll
-    for (int n = 0; n < P; ++n) hc[n] = h[c + n * M];
-    const int hist_len = (P - 1) * M;
+    for (int n = 0; n < P; ++n) hc[n] = n < p_real ? h[c + n * M] : 0.0f;
+    const int hist_len = (p_real - 1) * M;
     const long long x_len = (long long)nframes * M;
     const long long wg_first = (long long)blockIdx.x * G * run;
     const long long f_begin = wg_first + (long long)g * run;
@@ -676,7 +678,7 @@ firpfbch_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restric
 
 template <int P, int LGM>
 static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
-                                   cf32 *y, size_t nframes, hipStream_t st) {
+                                   cf32 *y, size_t nframes, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     size_t run = nframes / ((size_t)YG_COL_WGS * G);
@@ -691,9 +693,9 @@ static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float 
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
     if (nframes % ((size_t)G * run) == 0)            // every workgroup full (see launch_firpfbch_col)
-        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
+        firpfbch_syn_col_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, p_real);
     else
-        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
+        firpfbch_syn_col_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, p_real);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -704,13 +706,13 @@ int launch_firpfbch_syn(const cf32 *hist, const cf32 *x, const float *h, int M, 
     if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && nframes >= 64) {
 #define YG_SYN_CASE(PP)                                                                              \
     case PP:                                                                                         \
-        return M == 8 ? launch_firpfbch_syn_col<PP, 3>(hist, x, h, twM, y, nframes, st)              \
-             : M == 16 ? launch_firpfbch_syn_col<PP, 4>(hist, x, h, twM, y, nframes, st)             \
-             : M == 32 ? launch_firpfbch_syn_col<PP, 5>(hist, x, h, twM, y, nframes, st)             \
-             : M == 64 ? launch_firpfbch_syn_col<PP, 6>(hist, x, h, twM, y, nframes, st)             \
-             : M == 128 ? launch_firpfbch_syn_col<PP, 7>(hist, x, h, twM, y, nframes, st)            \
-                        : launch_firpfbch_syn_col<PP, 8>(hist, x, h, twM, y, nframes, st);
-        switch (p) {
+        return M == 8 ? launch_firpfbch_syn_col<PP, 3>(hist, x, h, twM, y, nframes, st, p)              \
+             : M == 16 ? launch_firpfbch_syn_col<PP, 4>(hist, x, h, twM, y, nframes, st, p)             \
+             : M == 32 ? launch_firpfbch_syn_col<PP, 5>(hist, x, h, twM, y, nframes, st, p)             \
+             : M == 64 ? launch_firpfbch_syn_col<PP, 6>(hist, x, h, twM, y, nframes, st, p)             \
+             : M == 128 ? launch_firpfbch_syn_col<PP, 7>(hist, x, h, twM, y, nframes, st, p)            \
+                        : launch_firpfbch_syn_col<PP, 8>(hist, x, h, twM, y, nframes, st, p);
+        switch (p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : 0) {   // zero-padded branch lengths (see launch_firpfbch)
             YG_SYN_CASE(4)
             YG_SYN_CASE(8)
             YG_SYN_CASE(16)
@@ -860,7 +862,7 @@ __global__ void __launch_bounds__(256)
 firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM, Pow2Plan plan,
                      int rank, int R, float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 16 */,
-                     float2 *__restrict__ hist_next) {
+                     float2 *__restrict__ hist_next, int p_real /* taps per branch, <= P: the rest are zero */) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LGM, lgM = LGM, G = 256 / M, M2 = M / 2;
     chan_write_next_hist(hist, hist_len, x, nsteps * (size_t)M2, hist_next);
@@ -881,8 +883,8 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 #pragma unroll
     for (int m = 0; m < P; ++m) {
         const int n0 = bpar ? (m + P - 1) % P : m;              // rotated for the late-fed half
-        h0r[m] = h[b + n0 * M];
-        h1[m] = h[i1 + m * M];
+        h0r[m] = n0 < p_real ? h[b + n0 * M] : 0.0f;            // branch lengths between the built sizes run zero-padded
+        h1[m] = m < p_real ? h[i1 + m * M] : 0.0f;
     }
     const float invM = 1.0f / (float)M;
     const long long x_len = (long long)nsteps * M2;
@@ -1015,7 +1017,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
 template <int P, int LGM>
 static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, const float *h,
                                 const cf32 *twM, int rank, int nranks, cf32 *y, size_t nsteps, hipStream_t st,
-                                cf32 *hist_next) {
+                                cf32 *hist_next, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     size_t run = nsteps / ((size_t)YG_COL_WGS * G);
@@ -1034,7 +1036,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const Pow2Plan plan = nranks > 1 ? make_pow2_plan(M / nranks) : Pow2Plan{0, {0}};
     const int rk = nranks > 1 ? rank : 0, nr = nranks > 1 ? nranks : 1;
     const unsigned grid = (unsigned)nblk;
-#define YG_C5_LAUNCH(SH, FU) firpfbch2_col_kernel<P, LGM, SH, FU><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn)
+#define YG_C5_LAUNCH(SH, FU) firpfbch2_col_kernel<P, LGM, SH, FU><<<grid, 256, lds, st>>>(fh, hist_len, fx, h, ftw, plan, rk, nr, fy, nsteps, (int)run, fn, p_real)
     if (nranks > 1) { if (full) YG_C5_LAUNCH(true, true); else YG_C5_LAUNCH(true, false); }
     else { if (full) YG_C5_LAUNCH(false, true); else YG_C5_LAUNCH(false, false); }
 #undef YG_C5_LAUNCH
@@ -1217,13 +1219,14 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
 #define YG_COL2_CASE(PP)                                                                                          \
     case PP:                                                                                                      \
         if (hist_written) *hist_written = hist_next != nullptr;                                                   \
-        return M == 8 ? launch_firpfbch2_col<PP, 3>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)       \
-             : M == 16 ? launch_firpfbch2_col<PP, 4>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
-             : M == 32 ? launch_firpfbch2_col<PP, 5>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
-             : M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)      \
-             : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next)     \
-                        : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next);
-        switch (p) {
+        return M == 8 ? launch_firpfbch2_col<PP, 3>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p)       \
+             : M == 16 ? launch_firpfbch2_col<PP, 4>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p)      \
+             : M == 32 ? launch_firpfbch2_col<PP, 5>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p)      \
+             : M == 64 ? launch_firpfbch2_col<PP, 6>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p)      \
+             : M == 128 ? launch_firpfbch2_col<PP, 7>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p)     \
+                        : launch_firpfbch2_col<PP, 8>(hist, hist_len, x, h, twM, rank, nranks, y, nsteps, st, hist_next, p);
+        // branch lengths between the built sizes (2m = 6, 10, 12, 14) take the next one with zero taps behind theirs
+        switch (p <= 2 ? 2 : p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : 0) {
             YG_COL2_CASE(2)
             YG_COL2_CASE(4)
             YG_COL2_CASE(8)
@@ -1322,7 +1325,8 @@ template <int P2, int LGM, bool FAST>
 __global__ void __launch_bounds__(256)
 firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                          const float *__restrict__ h, const float2 *__restrict__ twM,
-                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run) {
+                         unsigned long long step0, float2 *__restrict__ y, size_t nsteps, int run,
+                         int p2_real /* 4m <= P2: the other lags are zero */) {
     constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2;
     constexpr int R0 = (LGM == 3 || LGM == 5 || LGM == 6) ? 8 : 16, R1 = M / R0;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1338,8 +1342,8 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
     for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     float hk[P2];
 #pragma unroll
-    for (int k = 0; k < P2; ++k) hk[k] = 0.5f * h[i + (k & 1) * M2 + (k >> 1) * M];
-    const int hist_len = (P2 - 1) * M;
+    for (int k = 0; k < P2; ++k) hk[k] = k < p2_real ? 0.5f * h[i + (k & 1) * M2 + (k >> 1) * M] : 0.0f;
+    const int hist_len = (p2_real - 1) * M;
     const long long x_len = (long long)nsteps * M;
     const long long wg_first = (long long)blockIdx.x * G * run;
     const long long s_begin = wg_first + (long long)g * run;
@@ -1405,7 +1409,7 @@ firpfbch2_syn_col_kernel(const float2 *__restrict__ hist, const float2 *__restri
 
 template <int P2, int LGM>
 static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM, uint64_t step0,
-                                    cf32 *y, size_t nsteps, hipStream_t st) {
+                                    cf32 *y, size_t nsteps, hipStream_t st, int p2_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
     size_t run = nsteps / ((size_t)YG_COL_WGS * G);
@@ -1421,9 +1425,9 @@ static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float
     float2 *fy = reinterpret_cast<float2 *>(y);
     const unsigned long long s0 = (unsigned long long)step0;
     if (nsteps % ((size_t)G * run) == 0)             // every workgroup full (see launch_firpfbch_col)
-        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run);
+        firpfbch2_syn_col_kernel<P2, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, p2_real);
     else
-        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run);
+        firpfbch2_syn_col_kernel<P2, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, s0, fy, nsteps, (int)run, p2_real);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -1433,15 +1437,15 @@ int launch_firpfbch2_syn(const cf32 *hist, int hist_len, const cf32 *x, const fl
     if (nsteps == 0) return YAGI_OK;
     const int p = 2 * m, back = 2 * p - 1;
     if (hist_len != back * M) return fail(YAGI_ERR_INTERNAL, "firpfbch2 synthesizer: bad history length");
-    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && (m == 2 || m == 4) && nsteps >= 64) {
+    if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && m <= 4 && nsteps >= 64) {
 #define YG_SYN2_CASE(PP)                                                                                     \
-    (M == 8 ? launch_firpfbch2_syn_col<PP, 3>(hist, x, h, twM, step0, y, nsteps, st)                         \
-     : M == 16 ? launch_firpfbch2_syn_col<PP, 4>(hist, x, h, twM, step0, y, nsteps, st)                      \
-     : M == 32 ? launch_firpfbch2_syn_col<PP, 5>(hist, x, h, twM, step0, y, nsteps, st)                      \
-     : M == 64 ? launch_firpfbch2_syn_col<PP, 6>(hist, x, h, twM, step0, y, nsteps, st)                      \
-     : M == 128 ? launch_firpfbch2_syn_col<PP, 7>(hist, x, h, twM, step0, y, nsteps, st)                     \
-                : launch_firpfbch2_syn_col<PP, 8>(hist, x, h, twM, step0, y, nsteps, st))
-        return m == 2 ? YG_SYN2_CASE(8) : YG_SYN2_CASE(16);
+    (M == 8 ? launch_firpfbch2_syn_col<PP, 3>(hist, x, h, twM, step0, y, nsteps, st, 2 * p)                         \
+     : M == 16 ? launch_firpfbch2_syn_col<PP, 4>(hist, x, h, twM, step0, y, nsteps, st, 2 * p)                      \
+     : M == 32 ? launch_firpfbch2_syn_col<PP, 5>(hist, x, h, twM, step0, y, nsteps, st, 2 * p)                      \
+     : M == 64 ? launch_firpfbch2_syn_col<PP, 6>(hist, x, h, twM, step0, y, nsteps, st, 2 * p)                      \
+     : M == 128 ? launch_firpfbch2_syn_col<PP, 7>(hist, x, h, twM, step0, y, nsteps, st, 2 * p)                     \
+                : launch_firpfbch2_syn_col<PP, 8>(hist, x, h, twM, step0, y, nsteps, st, 2 * p))
+        return m <= 2 ? YG_SYN2_CASE(8) : YG_SYN2_CASE(16);     // 4m lags zero-padded to the ring of 8 or 16
 #undef YG_SYN2_CASE
     }
     int S = 4096 / M;
