@@ -35,7 +35,8 @@ def test_firpfbch_vs_oracle(ya, oracle, M, m):
 @pytest.mark.parametrize("M,m,nfr", [(64, 8, 4099), (64, 2, 1000), (128, 4, 777), (256, 8, 300), (256, 2, 64), (64, 4, 65),
                                      (512, 4, 333), (512, 2, 64), (1024, 2, 200), (1024, 4, 77), (512, 4, 20000),
                                      (8, 2, 5001), (16, 4, 3000), (32, 8, 2077), (8, 8, 70000),
-                                     (64, 3, 1000), (256, 5, 300), (16, 1, 2000), (128, 6, 500), (32, 7, 640)])
+                                     (64, 3, 1000), (256, 5, 300), (16, 1, 2000), (128, 6, 500), (32, 7, 640),
+                                     (512, 3, 500), (1024, 1, 300), (512, 1, 200), (1024, 3, 130)])
 def test_firpfbch_column_kernel_long_runs(ya, oracle, M, m, nfr):
     """the column-sliding kernels (M in {64,128,256}, p in {4,8,16}; wide banks M in {512,1024}, p in {4,8}): ragged
     frame counts, carried state; 20000 frames of 512 channels run several tiles per workgroup; branch lengths between the
@@ -97,7 +98,8 @@ def test_firpfbch2_vs_oracle(ya, oracle, M, m):
 @pytest.mark.parametrize("M,m,ns", [(256, 4, 1000), (256, 2, 64), (64, 4, 4098), (128, 1, 333), (64, 2, 200), (64, 8, 700),
                                     (128, 8, 130), (512, 2, 333), (512, 1, 64), (512, 4, 90), (1024, 1, 200), (1024, 2, 77),
                                     (512, 2, 20000), (8, 2, 5000), (16, 1, 3001), (32, 4, 2000), (8, 4, 70000),
-                                    (64, 3, 1000), (256, 5, 300), (128, 6, 500), (32, 7, 640), (256, 3, 2048)])
+                                    (64, 3, 1000), (256, 5, 300), (128, 6, 500), (32, 7, 640), (256, 3, 2048),
+                                    (512, 3, 400)])
 def test_firpfbch2_column_kernel_long_runs(ya, oracle, M, m, ns):
     """the column-sliding kernel (M in {64,128,256}, 2m in {2,4,8,16}, even first step) incl. ragged tails"""
     h = oracle.fir_design_kaiser(2 * M * m + 1, 1.0 / M, 60.0)

@@ -338,7 +338,7 @@ template <int P, int LGM, bool FULL>                // FULL: every workgroup of 
 __global__ void __launch_bounds__(256)
 firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ x,
                      const float *__restrict__ h, const float2 *__restrict__ twM,
-                     float2 *__restrict__ y, size_t nframes, int run) {
+                     float2 *__restrict__ y, size_t nframes, int run, int p_real /* <= P: the other taps are zero */) {
     constexpr int M = 1 << LGM, lgM = LGM, C = M / 256, HF = 4096 / M, TILE = 2 * HF;
     constexpr int R0 = LGM == 9 ? 8 : 16;                        // then 8 x 8
     constexpr int nq = HF, lgnq = LGM == 9 ? 3 : 2;
@@ -354,8 +354,8 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
 #pragma unroll
     for (int cc = 0; cc < C; ++cc)
 #pragma unroll
-        for (int n = 0; n < P; ++n) hc[cc][n] = h[(M - 1 - (t + 256 * cc)) + n * M];
-    const int hist_len = (P - 1) * M;
+        for (int n = 0; n < P; ++n) hc[cc][n] = n < p_real ? h[(M - 1 - (t + 256 * cc)) + n * M] : 0.0f;
+    const int hist_len = (p_real - 1) * M;
     const long long x_len = (long long)nframes * M;
     const long long f_begin = (long long)blockIdx.x * run;
     const long long left = (long long)nframes - f_begin;
@@ -422,7 +422,7 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
 
 template <int P, int LGM>
 static int launch_firpfbch_wide(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
-                                cf32 *y, size_t nframes, hipStream_t st) {
+                                cf32 *y, size_t nframes, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM, HF = 4096 / M, TILE = 2 * HF;
     size_t run = nframes / (size_t)YG_COL_WGS;
     run = run / TILE * TILE;
@@ -443,9 +443,9 @@ static int launch_firpfbch_wide(const cf32 *hist, const cf32 *x, const float *h,
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
     if (nframes % run == 0)
-        firpfbch_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
+        firpfbch_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, p_real);
     else
-        firpfbch_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run);
+        firpfbch_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, fx, h, ftw, fy, nframes, (int)run, p_real);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -458,11 +458,11 @@ int launch_firpfbch(const cf32 *hist, const cf32 *x, const float *h, int M, int 
                     const cf32 *twM, cf32 *y, size_t nframes, hipStream_t st, cf32 *hist_next, bool *hist_written) {
     if (hist_written) *hist_written = false;
     if (nframes == 0) return YAGI_OK;
-    if ((M == 512 || M == 1024) && (p == 4 || p == 8) && nframes >= 64) {
-        if (M == 512) return p == 4 ? launch_firpfbch_wide<4, 9>(hist, x, h, twM, y, nframes, st)
-                                    : launch_firpfbch_wide<8, 9>(hist, x, h, twM, y, nframes, st);
-        return p == 4 ? launch_firpfbch_wide<4, 10>(hist, x, h, twM, y, nframes, st)
-                      : launch_firpfbch_wide<8, 10>(hist, x, h, twM, y, nframes, st);
+    if ((M == 512 || M == 1024) && p <= 8 && nframes >= 64) {     // p < 8 other than 4: zero taps behind the real ones
+        if (M == 512) return p <= 4 ? launch_firpfbch_wide<4, 9>(hist, x, h, twM, y, nframes, st, p)
+                                    : launch_firpfbch_wide<8, 9>(hist, x, h, twM, y, nframes, st, p);
+        return p <= 4 ? launch_firpfbch_wide<4, 10>(hist, x, h, twM, y, nframes, st, p)
+                      : launch_firpfbch_wide<8, 10>(hist, x, h, twM, y, nframes, st, p);
     }
     if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && nframes >= 64) {
 #define YG_COL_CASE(PP)                                                                              \
@@ -1050,7 +1050,8 @@ template <int P, int LGM, bool FULL>                // FULL: every workgroup of 
 __global__ void __launch_bounds__(256)
 firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ x,
                       const float *__restrict__ h, const float2 *__restrict__ twM,
-                      float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 2*HS */) {
+                      float2 *__restrict__ y, size_t nsteps, int run /* steps, multiple of 2*HS */,
+                      int p_real /* <= P: the other taps are zero */) {
     constexpr int M = 1 << LGM, lgM = LGM, M2 = M / 2, C = M / 256, HS = 4096 / M, TILE = 2 * HS, HP = HS / 2;
     constexpr int R0 = LGM == 9 ? 8 : 16;
     constexpr int nq = HS, lgnq = LGM == 9 ? 3 : 2;
@@ -1073,8 +1074,8 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
 #pragma unroll
         for (int m = 0; m < P; ++m) {
             const int n0 = bpar ? (m + P - 1) % P : m;           // rotated for the late-fed half
-            h0r[cc][m] = h[b + n0 * M];
-            h1[cc][m] = h[i1 + m * M];
+            h0r[cc][m] = n0 < p_real ? h[b + n0 * M] : 0.0f;
+            h1[cc][m] = m < p_real ? h[i1 + m * M] : 0.0f;
         }
     }
     const float invM = 1.0f / (float)M;
@@ -1167,7 +1168,7 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
 
 template <int P, int LGM>
 static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, const float *h, const cf32 *twM,
-                                 cf32 *y, size_t nsteps, hipStream_t st) {
+                                 cf32 *y, size_t nsteps, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM, HS = 4096 / M, TILE = 2 * HS;
     size_t run = nsteps / (size_t)YG_COL_WGS;
     run = run / TILE * TILE;
@@ -1188,9 +1189,9 @@ static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, 
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y);
     if (nsteps % run == 0)
-        firpfbch2_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run);
+        firpfbch2_wide_kernel<P, LGM, true><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run, p_real);
     else
-        firpfbch2_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run);
+        firpfbch2_wide_kernel<P, LGM, false><<<(unsigned)nblk, 256, lds, st>>>(fh, hist_len, fx, h, ftw, fy, nsteps, (int)run, p_real);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -1206,13 +1207,13 @@ int launch_firpfbch2(const cf32 *hist, int hist_len, const cf32 *x, const float 
     const size_t lead = (size_t)(p - 1) * M + M2;
     if ((size_t)hist_len != lead) return fail(YAGI_ERR_INTERNAL, "firpfbch2: bad history length");
     if (nranks == 1 && (step0 & 1) == 0 && nsteps >= 64 &&
-        ((M == 512 && (p == 2 || p == 4 || p == 8)) || (M == 1024 && (p == 2 || p == 4)))) {
+        ((M == 512 && p <= 8) || (M == 1024 && p <= 4))) {           // p = 6: zero taps behind the real ones
         if (M == 512)
-            return p == 2 ? launch_firpfbch2_wide<2, 9>(hist, hist_len, x, h, twM, y, nsteps, st)
-                 : p == 4 ? launch_firpfbch2_wide<4, 9>(hist, hist_len, x, h, twM, y, nsteps, st)
-                          : launch_firpfbch2_wide<8, 9>(hist, hist_len, x, h, twM, y, nsteps, st);
-        return p == 2 ? launch_firpfbch2_wide<2, 10>(hist, hist_len, x, h, twM, y, nsteps, st)
-                      : launch_firpfbch2_wide<4, 10>(hist, hist_len, x, h, twM, y, nsteps, st);
+            return p <= 2 ? launch_firpfbch2_wide<2, 9>(hist, hist_len, x, h, twM, y, nsteps, st, p)
+                 : p <= 4 ? launch_firpfbch2_wide<4, 9>(hist, hist_len, x, h, twM, y, nsteps, st, p)
+                          : launch_firpfbch2_wide<8, 9>(hist, hist_len, x, h, twM, y, nsteps, st, p);
+        return p <= 2 ? launch_firpfbch2_wide<2, 10>(hist, hist_len, x, h, twM, y, nsteps, st, p)
+                      : launch_firpfbch2_wide<4, 10>(hist, hist_len, x, h, twM, y, nsteps, st, p);
     }
     if ((M == 8 || M == 16 || M == 32 || M == 64 || M == 128 || M == 256) && (step0 & 1) == 0 && nsteps >= 64 &&
         is_pow2(M / nranks)) {
