@@ -1044,7 +1044,8 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     return YAGI_OK;
 }
 
-// firpfbch2, column-sliding form for wide banks (M = 512, 1024; 2m in {2, 4}): every lane owns M/256 windows
+// firpfbch2, column-sliding form for wide banks (M = 512: 2m <= 8, M = 1024: 2m <= 4; built for 2 / 4 / 8, zero taps
+// behind shorter branches): every lane owns M/256 windows
 // b = t + 256 cc (so the early/late-fed split b >= M/2 is uniform per cc), half tiles of HS = 4096/M steps.
 template <int P, int LGM, bool FULL>                // FULL: every workgroup of the launch holds `run` steps (see firpfbch_col_kernel)
 __global__ void __launch_bounds__(256)
@@ -1317,7 +1318,8 @@ firpfbch2_syn_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     }
 }
 
-// Column-sliding firpfbch2 synthesizer (M in {8..256}, m in {2, 4}): firpfbch_syn_col_kernel with a ring of 4m steps per
+// Column-sliding firpfbch2 synthesizer (M in {8..256}, m <= 4: rings of 8 and 16 steps, 4m zero-padded to them):
+// firpfbch_syn_col_kernel with a ring of 4m steps per
 // column.  Column c of the inverse-transformed steps feeds output i = c mod M/2 -- on the steps whose parity f selects
 // its half (b = i + f M/2 = c) -- with the taps of lag k: hk[k] = h[i + (k & 1) M/2 + (k >> 1) M] (lag 2n: first sum, lag
 // 2n + 1: second sum; added in lag order like the tiled kernel).  For M >= 128 a wave is all-lower or all-upper half:
