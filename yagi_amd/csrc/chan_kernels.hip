@@ -265,7 +265,19 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
         stockham_pass<R0, -1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
         __syncthreads();
         const float2 *res = vb;
-        if constexpr (R1 > 1) {
+        if constexpr (R1 >= 8 && M / R1 >= 16) {
+            // last pass straight from registers to y: 16-lane runs of 128 contiguous bytes (M = 128, 256); no barrier
+            // behind it: the next half tile writes va first, and its own barrier stands between this pass's reads of vb
+            // and the next writes to it (as in firpfbch2_col_kernel)
+            stockham_last_pass_out<R1, -1>(vb, M, nq, twl, 1, true, pitch, [&](int q, int k, float2 v) {
+                const int gq = q / kColHalf, fr = q - gq * kColHalf;
+                if constexpr (FULL)
+                    buf_st(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), v);
+                else if (t + fr < group_frames(gq))
+                    yb[((unsigned)(gq * run + t + fr) << lgM) + k] = v;
+            });
+            return;
+        } else if constexpr (R1 > 1) {
             stockham_pass<R1, -1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
             __syncthreads();
             res = va;
