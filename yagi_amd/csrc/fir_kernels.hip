@@ -378,9 +378,25 @@ fir_decim_consec_kernel(const typename K::T *__restrict__ win, const typename K:
     // samples come through a buffer descriptor of exactly `total` entries (entries past it are range-checked away, never read):
     // no address arithmetic per entry -- the generic staging below spent as many vector instructions as the taps.
     const int lgM = 31 - __builtin_clz((unsigned)M);
-    const bool fast = inside && (M & (M - 1)) == 0 && M <= NT && ((NT >> lgM) & (R - 1)) == 0 &&
-                      (unsigned long long)total * sizeof(T) < 0xffffffffull;
-    if (fast) {
+    const bool desc = inside && (unsigned long long)total * sizeof(T) < 0xffffffffull;
+    const bool fast = desc && (M & (M - 1)) == 0 && M <= NT && ((NT >> lgM) & (R - 1)) == 0;
+    if (desc && !fast) {
+        // any other M: the same descriptor loads, the (row, phase) of an entry advanced incrementally per trip
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + base, (unsigned)((size_t)total * sizeof(T)));
+        const unsigned vo = (unsigned)sizeof(T) * threadIdx.x;
+        for (int t0 = 0; t0 * NT < total; t0 += 8) {
+            T r[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                r[it] = buf_ld_t<T>(rx, vo + (unsigned)sizeof(T) * NT * (unsigned)(t0 + it), 0u);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                if ((int)threadIdx.x + NT * (t0 + it) < total) xs[ph * pitch + jj + (jj >> LG)] = r[it];
+                jj += djj; ph += dph;
+                if (ph >= M) { ph -= M; ++jj; }
+            }
+        }
+    } else if (fast) {
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + base, (unsigned)((size_t)total * sizeof(T)));
         const unsigned vo = (unsigned)sizeof(T) * threadIdx.x;
         const int rows = NT >> lgM;                              // row entries per trip
