@@ -221,13 +221,16 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
         long long lo = tile * kMsTile;
 #pragma unroll
         for (int k = S - 1; k >= 1; --k) lo = 2 * (lo - (2 * a.m[k] - 1));
-        const long long u0 = lo - (m20 - 1);
+        const long long u0 = lo - (m20 - 1);                        // pair index of the tile's stream entry 0
+        const long long ub0 = u0 > 0 ? u0 : 0;                       // first pair that exists
+        const T *xb = x + 2 * ub0;                                   // uniform base; the lanes add 32-bit offsets
+        const int shift = (int)(ub0 - u0), rmax = (int)(npairs - 1 - ub0);
 #pragma unroll
         for (int b = 0; b < NP; ++b) {
-            long long u = u0 + (long long)threadIdx.x + 256 * b;
-            u = u < 0 ? 0 : (u < npairs ? u : npairs - 1);
-            qe[b] = x[2 * u];
-            qo[b] = x[2 * u + 1];
+            int r = (int)threadIdx.x + 256 * b - shift;              // entries below zero are replaced at commit,
+            r = r < 0 ? 0 : (r < rmax ? r : rmax);                   // those past the block's end are never used
+            qe[b] = xb[2 * r];
+            qo[b] = xb[2 * r + 1];
         }
     };
     if (tile0 < tend) issue(tile0);
@@ -249,16 +252,17 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
         {
             const long long u0 = ua[0] - (m20 - 1);
             const int cnt = (int)(ub[0] - u0);
-#pragma unroll
-            for (int b = 0; b < NP; ++b) {
+            const int nneg = u0 < 0 ? (int)(-u0 < (long long)cnt ? -u0 : (long long)cnt) : 0;   // entries below index zero
+            const int soff = u0 < 0 ? (int)(m20 + u0) : 0;           // window slot of entry 0 (may lie before the windows:
+#pragma unroll                                                       // a halo reaches further back than they do near the
+            for (int b = 0; b < NP; ++b) {                           // block's start; those entries are never used)
                 const int j = (int)threadIdx.x + 256 * b;
                 if (j < cnt) {
-                    const long long u = u0 + j;
                     T e = qe[b], o = qo[b];
-                    if (u < 0) {                                 // a halo reaches further back than the stage's windows
-                        const bool held = u >= -m20;             // near the block's start: those entries are never used
-                        o = held ? a.state[0][m20 + u] : zero_of<T>();
-                        e = held ? a.state[0][m20 + m20 + u] : zero_of<T>();
+                    if (j < nneg) {
+                        const bool held = soff + j >= 0;
+                        o = held ? a.state[0][soff + j] : zero_of<T>();
+                        e = held ? a.state[0][m20 + soff + j] : zero_of<T>();
                     }
                     S0[0][j] = o;
                     S1[0][j] = e;
@@ -282,11 +286,11 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
                 v0 = ua[kn] - (m2n - 1);                              // pair index of the next stage's entry 0
                 if (v0 < 0) {
                     const int nneg = (int)(-v0 < ub[kn] - v0 ? -v0 : ub[kn] - v0);
+                    const int soff = (int)(m2n + v0);                 // window slot of entry 0 (see the stage-0 fill)
                     for (int j = threadIdx.x; j < nneg; j += 256) {
-                        const long long v = v0 + j;
-                        const bool held = v >= -m2n;                  // see the stage-0 fill
-                        S0[kn][j] = held ? a.state[kn][m2n + v] : zero_of<T>();
-                        S1[kn][j] = held ? a.state[kn][m2n + m2n + v] : zero_of<T>();
+                        const bool held = soff + j >= 0;
+                        S0[kn][j] = held ? a.state[kn][soff + j] : zero_of<T>();
+                        S1[kn][j] = held ? a.state[kn][m2n + soff + j] : zero_of<T>();
                     }
                 }
             }
@@ -311,11 +315,10 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 const int m2 = 2 * a.m[k];
-                const long long u0 = ua[k] - (m2 - 1);
+                const int e0 = (int)(ub[k] - m2 - (ua[k] - (m2 - 1)));   // stream entry of pair ub_k - 2m (>= 0: the tile holds an output)
                 for (int j = threadIdx.x; j < m2; j += 256) {
-                    const long long u = ub[k] - m2 + j;               // >= u0: the tile holds at least one output
-                    a.state_next[k][j] = S0[k][u - u0];
-                    a.state_next[k][m2 + j] = S1[k][u - u0];
+                    a.state_next[k][j] = S0[k][e0 + j];
+                    a.state_next[k][m2 + j] = S1[k][e0 + j];
                 }
             }
         }
