@@ -1,4 +1,4 @@
-// chan_kernels.hip -- polyphase channelizers multichannel::firpfbch / firpfbch2 (analyzers).
+// chan_kernels.hip -- polyphase channelizers multichannel::firpfbch / firpfbch2: analyzers and synthesizers (tiled, column-sliding and wide forms).
 //
 // The reference module is EMPTY (src/multichannel/mod.rs, 0 lines; LIQUID_COMPAT.md:1765-1798),
 // so these kernels implement liquid-dsp's published semantics composed from the reference's own
