@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Occupancy probe (diagnostic build that adds YG_X bytes of dynamic LDS to the fft4096 / frequency-domain launches):
-streamed 2^28 samples, per 2^24-sample block."""
+"""Occupancy probe: streamed 2^28 samples, us per 2^24-sample block, for the plain 4096-point transform and the
+frequency-domain stream kernel at 4 / 3 / 2 workgroups per CU.
+Needs a diagnostic build of the library (not in the tree) in which the two launches take their dynamic-LDS size from
+the environment -- in fft_kernels.hip `fft4096_kernel<-1><<<grid, 256, getenv("YG_X") ? atoi(getenv("YG_X")) : 0, st>>>`
+and the same third launch argument in freq_kernels.hip's `firfft_crcf_4096_freq_kernel<<<...>>>`; point YAGI_HIP_LIB
+at it.  Output of the round-2 run: profiles/r02_occupancy_probe.txt."""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
