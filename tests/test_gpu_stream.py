@@ -175,3 +175,52 @@ def test_stream_pure_delay_whole_block(ya, delay):
         ya.synchronize()
         assert rel_l2(dy.to_numpy(extra * nfft), ref[n:]) <= 2e-6, variant
         dy.free()
+
+
+def test_stream_pipelined_blocks_bit_identical(ya, oracle):
+    """set_pipeline(1): consecutive execute_dev calls run on two streams of the object (window copied out ahead of the
+    block kernel); after join() the spectra are bit for bit those of the unpipelined calls -- every block seam, ragged
+    block lengths, a scale change, reset, and a host-pointer call in between"""
+    h = oracle.fir_design_kaiser(256, 0.2, 60.0)
+    sizes = [64, 1, 7, 64, 2, 128, 33, 64, 64, 64, 5, 64]
+    nf = sum(sizes)
+    dx = ya.gen_complex_dev(SEED + 2, nf * 4096)
+    plain, piped = ya.FirFftStream(h), ya.FirFftStream(h)
+    for q in (plain, piped):
+        q.set_scale(0.4)
+    piped.set_pipeline(True)
+    dy0, dy1 = ya.DeviceArray(nf * 4096, np.complex64), ya.DeviceArray(nf * 4096, np.complex64)
+    dy1.zero()
+    ya.synchronize()
+    for rep in range(3):
+        for q, dy in ((plain, dy0), (piped, dy1)):
+            f0 = 0
+            for s in sizes:
+                q.execute_dev(dx.ptr + 8 * 4096 * f0, s, dy.ptr + 8 * 4096 * f0)
+                f0 += s
+        piped.join()                                   # the null stream now waits for both lanes: no device sync needed
+        a, b = dy0.to_numpy(), dy1.to_numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), rep
+        if rep == 0:                                   # frames at a seam and inside a block against the f64 truth
+            src = dx.to_numpy()
+            for f in (0, 64, 65, 72, 500):
+                lo = max(0, f * 4096 - 255)
+                xs = src[lo:(f + 1) * 4096]
+                if f == 0:
+                    xs = np.concatenate([np.zeros(255, np.complex64), xs])
+                truth = np.fft.fft(oracle.fir_block_f64("crcf", h, xs, scale=0.4)[-4096:])
+                assert rel_l2(b[f * 4096:(f + 1) * 4096], truth) <= 1e-5, f
+        if rep == 0:
+            for q in (plain, piped):
+                q.set_scale(0.25)                      # scaled FFT{h} is rebuilt on the object's stream: that call joins
+        if rep == 1:
+            for q in (plain, piped):
+                q.reset()
+    # host-pointer call after pipelined device calls continues the same stream
+    x2 = oracle.gen_complex(SEED + 9, 3 * 4096)
+    assert np.array_equal(plain.execute(x2).view(np.uint32), piped.execute(x2).view(np.uint32))
+    piped.set_pipeline(False)
+    plain.execute_dev(dx, 8, dy0)
+    piped.execute_dev(dx, 8, dy1)
+    ya.synchronize()
+    assert np.array_equal(dy0.to_numpy(8 * 4096).view(np.uint32), dy1.to_numpy(8 * 4096).view(np.uint32))

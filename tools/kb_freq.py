@@ -21,7 +21,8 @@ n = NF * 4096
 dev = torch.device("cuda")
 x = torch.empty(NB * n, dtype=torch.complex64, device=dev)
 y = torch.empty(NB * n, dtype=torch.complex64, device=dev)
-st = torch.cuda.current_stream()
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
 ya.gen_complex_dev(0x59414749 + 2, NB * n, out=x, stream=st.cuda_stream)
 h = ya.fir_design_kaiser(256, 0.2, 60.0)
 xp, yp = x.data_ptr(), y.data_ptr()
@@ -31,14 +32,17 @@ blocks = [(xp + 8 * n * b, yp + 8 * n * b) for b in range(NB)]
 def make(form):
     q = ya.FirFftStream(h)
     q.set_scale(0.4)
-    q.set_variant(form)
+    q.set_variant(form % 100)
     q.set_stream(st.cuda_stream)
+    if form >= 100:                 # 104 = variant 4 with pipelined block calls (two streams of the object)
+        q.set_pipeline(True)
     return q
 
 
 def run(q):
     for xb, yb in blocks:
         q.execute_dev(xb, NF, yb)
+    q.join()
 
 
 def check(form):

@@ -961,6 +961,14 @@ class FirFftStream(_Handle):
     def execute_dev(self, x_dev, nframes, spectra_dev):
         _check(lib.yagi_hip_firfft_crcf_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(spectra_dev)))
 
+    def set_pipeline(self, on=True):
+        """pipelined block calls: consecutive execute_dev calls overlap on two streams owned by the object;
+        their outputs are ordered on the object's stream only after join() (include/yagi_hip.h)"""
+        _check(lib.yagi_hip_firfft_crcf_set_pipeline(self._h, 1 if on else 0))
+
+    def join(self):
+        _check(lib.yagi_hip_firfft_crcf_join(self._h))
+
 
 # ---- channelizers (absent from the reference; see include/yagi_hip.h) ---------------------------
 class FirPfbCh(_Handle):

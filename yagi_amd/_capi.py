@@ -212,6 +212,8 @@ _sig("yagi_hip_firfft_crcf_reset", vp)
 _sig("yagi_hip_firfft_crcf_set_variant", vp, ci)
 _sig("yagi_hip_firfft_crcf_execute", vp, vp, sz, vp)
 _sig("yagi_hip_firfft_crcf_execute_dev", vp, vp, sz, vp)
+_sig("yagi_hip_firfft_crcf_set_pipeline", vp, ci)
+_sig("yagi_hip_firfft_crcf_join", vp)
 
 _sig("yagi_hip_firpfbch_crcf_create", sz, sz, vp, pvp)
 _sig("yagi_hip_firpfbch_crcf_create_kaiser", sz, sz, f32, pvp)

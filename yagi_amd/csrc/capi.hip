@@ -59,15 +59,15 @@ static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
 template <class T>
 struct DevWindow {
     int len = 0;
-    DevBuf buf[2];
+    static constexpr int kBufs = 3;   // a ring of three: the pipelined stream (FirFft) writes window b+1 while block b reads window b
+    DevBuf buf[kBufs];
     int cur = 0;
     std::vector<T> pending;
     DevBuf stage;
 
     int init(int n, hipStream_t st) {
         len = n;
-        YG_TRY(buf[0].alloc((size_t)n * sizeof(T)));
-        YG_TRY(buf[1].alloc((size_t)n * sizeof(T)));
+        for (auto &b : buf) YG_TRY(b.alloc((size_t)n * sizeof(T)));
         return reset(st);
     }
     int reset(hipStream_t st) {
@@ -77,13 +77,13 @@ struct DevWindow {
     }
     const T *dev() const { return buf[cur].template as<T>(); }
     // for kernels that write the next window themselves: the other buffer, then flip()
-    T *next() { return buf[1 - cur].template as<T>(); }
-    void flip() { cur = 1 - cur; }
+    T *next() { return buf[(cur + 1) % kBufs].template as<T>(); }
+    void flip() { cur = (cur + 1) % kBufs; }
     // window <- last len of (window ++ x_dev[0..n))
     int advance(const T *x_dev, size_t n, hipStream_t st) {
         if (n == 0) return YAGI_OK;
-        YG_TRY(launch_update_window<T>(dev(), x_dev, n, len, buf[1 - cur].template as<T>(), st));
-        cur = 1 - cur;
+        YG_TRY(launch_update_window<T>(dev(), x_dev, n, len, next(), st));
+        flip();
         return YAGI_OK;
     }
     void push(T v) {
@@ -572,6 +572,37 @@ int FirFilt<K>::prepare_conv() {
 // ---------------------------------------------------------------------------------------------
 // fused firfilt_crcf -> FFT stream
 // ---------------------------------------------------------------------------------------------
+// Pipelined block calls (yagi_hip_firfft_crcf_set_pipeline).  Consecutive blocks of the stream depend on each other
+// only through the L-sample filter window, and that window is INPUT data (the previous block's last L samples), which
+// the pipelined contract keeps intact until the join: block b + 1 reads it straight from the previous call's x, so it
+// needs nothing block b computes.  The block kernels alternate between two streams owned by the handle; call b does
+//     caller's stream: record `in`           lane b & 1: wait(in), block kernel b, record done[b & 1]
+// so block b + 1 ramps up while block b drains (on one stream every kernel waits for the complete drain of the one
+// before it: ~4 us of a 61 us block).  The caller's stream is NOT made to wait per call (its next `in` would inherit
+// that wait and serialise the blocks); it joins the lanes in yagi_hip_firfft_crcf_join, which every other entry point
+// of the object calls first and which also copies the last block's tail into the object's window.
+struct StreamPipe {
+    bool on = false;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t in = nullptr, done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    unsigned calls = 0;
+    const cf32 *prev_tail = nullptr;      // last L samples of the previous pipelined block (null: use the object's window)
+    int init() {
+        if (lane[0]) return YAGI_OK;
+        for (auto &s : lane) YG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        YG_HIP(hipEventCreateWithFlags(&in, hipEventDisableTiming));
+        for (auto &e : done) YG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return YAGI_OK;
+    }
+    ~StreamPipe() {
+        for (auto &s : lane)
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (in) (void)hipEventDestroy(in);
+        for (auto &e : done) if (e) (void)hipEventDestroy(e);
+    }
+};
+
 struct FirFft {
     FirFilt<CRCF> fir;
     size_t nfft = 0;
@@ -580,6 +611,20 @@ struct FirFft {
     int variant = 0;
     DevBuf xin, yout;
     DevBuf scratch;            // variant 3: the FIR output stream between the two kernels
+    StreamPipe pipe;
+    // the caller's stream waits for every block handed to the lanes, then takes over the filter window
+    int join() {
+        for (int i = 0; i < 2; ++i) {
+            if (pipe.busy[i]) YG_HIP(hipStreamWaitEvent(fir.st, pipe.done[i], 0));
+            pipe.busy[i] = false;
+        }
+        if (pipe.prev_tail) {
+            YG_TRY(launch_update_window<cf32>(fir.w.dev(), pipe.prev_tail, (size_t)fir.L, fir.L, fir.w.next(), fir.st));
+            fir.w.flip();
+            pipe.prev_tail = nullptr;
+        }
+        return YAGI_OK;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2147,15 +2192,31 @@ int yagi_hip_firfft_crcf_create(const float *h, size_t h_len, size_t nfft, yagi_
     return YAGI_OK;
 } catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) try { delete q; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_set_pipeline(yagi_hip_firfft_crcf q, int on) try {
+    CHECK_Q(q);
+    YG_TRY(q->join());
+    if (on) YG_TRY(q->pipe.init());
+    q->pipe.on = on != 0;
+    return YAGI_OK;
+} catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_join(yagi_hip_firfft_crcf q) try {
+    CHECK_Q(q);
+    return q->join();
+} catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firfft_crcf_set_stream(yagi_hip_firfft_crcf q, yagi_stream_t s) try {
     CHECK_Q(q);
     if (q->fir.st == to_stream(s)) return YAGI_OK;
+    YG_TRY(q->join());
     YG_HIP(hipStreamSynchronize(q->fir.st));
     q->fir.st = to_stream(s);
     return YAGI_OK;
 } catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firfft_crcf_set_scale(yagi_hip_firfft_crcf q, float scale) try { CHECK_Q(q); q->fir.scale = scale; return YAGI_OK; } catch (...) { return ::yagi::api_exception(); }
-int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) try { CHECK_Q(q); return q->fir.w.reset(q->fir.st); } catch (...) { return ::yagi::api_exception(); }
+int yagi_hip_firfft_crcf_reset(yagi_hip_firfft_crcf q) try {
+    CHECK_Q(q);
+    YG_TRY(q->join());
+    return q->fir.w.reset(q->fir.st);
+} catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) try {
     CHECK_Q(q);
     if (variant < 0 || variant > 4) return fail(YAGI_ERR_CONFIG, "unknown variant %d", variant);
@@ -2165,6 +2226,7 @@ int yagi_hip_firfft_crcf_set_variant(yagi_hip_firfft_crcf q, int variant) try {
     if (variant == 4 && q->fir.L > 257) return fail(YAGI_ERR_CONFIG, "frequency-domain variant needs <= 257 taps");
     if (variant == 2 && !q->fir.Lm) return fail(YAGI_ERR_CONFIG, "MFMA variant needs <= 256 taps");
     if (variant == 1 && q->fir.Lp > kSlideMaxTaps) return fail(YAGI_ERR_CONFIG, "sliding variant needs <= %d taps", kSlideMaxTaps);
+    YG_TRY(q->join());
     q->variant = variant;
     return YAGI_OK;
 } catch (...) { return ::yagi::api_exception(); }
@@ -2175,6 +2237,10 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_PTR(spectra);
     CHECK_NOALIAS(x, nframes * q->nfft, spectra, nframes * q->nfft);
     auto &f = q->fir;
+    const bool use_freq = q->nfft == 4096 && (q->variant == 4 || (q->variant == 0 && f.L <= 257));
+    const bool piped = q->pipe.on && use_freq && f.w.pending.empty() && f.conv_ready && f.hfreq_s_valid &&
+                       f.hfreq_s_scale == f.scale;
+    if (!piped) YG_TRY(q->join());        // everything below runs on the caller's stream
     YG_TRY(f.w.flush(f.st));
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
     // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
@@ -2188,7 +2254,22 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         YG_TRY(launch_fft_batch(q->plan.d, ys, spectra, nframes, f.st));
         return f.w.advance(x, n, f.st);
     }
-    const bool use_freq = q->variant == 4 || (q->variant == 0 && f.L <= 257);
+    if (piped) {
+        // the frequency-domain kernel on lane b & 1 (see StreamPipe); tables and scaled FFT{h} are in place
+        auto &p = q->pipe;
+        const int i = (int)(p.calls & 1u);
+        const size_t n = nframes * q->nfft;
+        YG_HIP(hipEventRecord(p.in, f.st));
+        YG_HIP(hipStreamWaitEvent(p.lane[i], p.in, 0));
+        YG_TRY(launch_firfft_crcf_4096_freq(p.prev_tail ? p.prev_tail : f.w.dev(), x, f.hfreq_s.as<cf32>(),
+                                            f.gcorr.as<float>(), f.scale, f.L, q->tw.as<cf32>(), spectra, nullptr,
+                                            nframes, p.lane[i]));
+        YG_HIP(hipEventRecord(p.done[i], p.lane[i]));
+        p.busy[i] = true;
+        ++p.calls;
+        p.prev_tail = x + (n - (size_t)f.L);       // n >= 4096 > L
+        return YAGI_OK;
+    }
     if (use_freq) {
         // frequency-domain form (one kernel, 16 B/sample): FFT{h}.FFT{x_f} + FFT{frame-boundary correction}
         YG_TRY(f.prepare_conv());
@@ -2231,10 +2312,12 @@ int yagi_hip_firfft_crcf_execute(yagi_hip_firfft_crcf q, const yagi_cf32 *x, siz
     CHECK_PTR(x);
     CHECK_PTR(spectra);
     const size_t bytes = nframes * q->nfft * sizeof(cf32);
+    YG_TRY(q->join());
     YG_TRY(q->xin.ensure(bytes));
     YG_TRY(q->yout.ensure(bytes));
     YG_TRY(upload(q->xin.p, x, bytes, q->fir.st));
     YG_TRY(yagi_hip_firfft_crcf_execute_dev(q, q->xin.as<cf32>(), nframes, q->yout.as<cf32>()));
+    YG_TRY(q->join());
     return download(spectra, q->yout.p, bytes, q->fir.st);
 } catch (...) { return ::yagi::api_exception(); }
 

@@ -215,7 +215,7 @@ __device__ __forceinline__ void freq_head256(const float2 *__restrict__ xs, floa
 
 // hs = scale * FFT_4096{[h; 0]}; gcorr[j] = h[L-1-j] for j < L-1, zero beyond (256 floats); tw = the stream twiddle
 // table (capi.hip make_stream_twiddles: W_4096^m, then rows W^{t 2^k} (k < 4), W^{(t&15)(t>>4)}, W_256^{(t&15)(t>>4)});
-// win_next receives the L-sample filter window after the call (last L samples of x).
+// win_next receives the L-sample filter window after the call (last L samples of x); null = the caller produces it.
 __global__ void __launch_bounds__(256, 4)
 firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                              const float2 *__restrict__ hs, const float *__restrict__ gcorr, float scale, int L,
@@ -244,7 +244,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     if (t < 32) gl[256 + t] = 0.f;
     lds[kOffT256 + (t >> 4) * kTRow + (t & 15u)] = tw_t;
     freq_wait_corr<16>(dp_, dq_);
-    if (f == nframes - 1) {                          // new filter window = last L samples of the call
+    if (f == nframes - 1 && win_next) {              // new filter window = last L samples of the call (pipelined calls: written ahead by a launch of its own)
         const float2 *xf = x + (size_t)f * 4096;
         for (int i = t; i < L; i += 256) win_next[i] = xf[4096 - L + i];
     }
