@@ -30,7 +30,7 @@ data-path collective => "scaling": "weak"; value = all ranks' samples / max time
 `--workload c5` instead runs the one path with an exchange step: the firpfbch2 256-channel analyzer with its
 sub-bands sharded over the ranks, RCCL all-gather, assemble (strong scaling: the 2^26-sample block is fixed).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).
@@ -39,6 +39,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -91,7 +92,7 @@ def cpu_baseline(h, scale, budget_s=8.0, threads=None):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    T = max(1, min(threads or 16, avail))
+    T = max(1, min(threads or avail, avail))
     per = 512                                                      # frames per thread and pass
     passes = max(1, int(round(single * 1e6 * budget_s / 1.5 / (per * NFFT))))
     halo = TAPS - 1
@@ -124,6 +125,46 @@ def cpu_baseline(h, scale, budget_s=8.0, threads=None):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process stays GPU-free (no torch.cuda, no HIP call), starts
+    one fresh rank process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), lets them write to
+    this process's stdout / stderr (rank 0 prints the JSON line) and returns the worst exit code."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    worst, deadline = 0, None
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            live.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                deadline = deadline or time.time() + 30.0      # a rank died: the others cannot finish their collectives
+        if deadline and time.time() > deadline:
+            for pr in live:                                     # exactly the processes started above
+                pr.send_signal(signal.SIGTERM)
+            time.sleep(5.0)
+            for pr in live:
+                if pr.poll() is None:
+                    pr.kill()
+            worst = worst or 1
+            break
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,13 +186,19 @@ def main():
                          "4 frequency-domain filter with frame-boundary correction (one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (configs, other algorithms)")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU leg")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the all-cores CPU leg (0 = every core this process may run on)")
     ap.add_argument("--c5-chunks", type=int, default=8, help="--workload c5: chunks per block (gather of chunk k "
                                                               "overlaps the shard kernel of chunk k+1)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend for the barrier / max-over-ranks reduction (nccl = RCCL; "
                          "gloo lets several ranks share one GPU when rehearsing the N>1 path on a 1-GPU box)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="headline through plain block calls on one stream instead of the pipelined calls "
+                         "(yagi_hip_firfft_crcf_set_pipeline: consecutive blocks overlap on two streams of the object)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -211,11 +258,14 @@ def main():
     scale = 0.4
     x = torch.empty(ntot, dtype=torch.complex64, device=dev)
     y = torch.empty(ntot, dtype=torch.complex64, device=dev)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()                      # the launch stream: every event below is recorded on it
+    torch.cuda.set_stream(stream)
     q = ya.FirFftStream(h, NFFT)
     q.set_scale(scale)
     q.set_variant(args.variant)
     q.set_stream(stream.cuda_stream)
+    pipelined = eff_variant == 4 and not args.no_pipeline
+    q.set_pipeline(pipelined)
     # each rank filters its own stream: rank r's samples are draws [r*2^40 + ...) of the generator
     ya.gen_complex_dev(SEED, ntot, out=x, first=rank << 40, stream=stream.cuda_stream)
     torch.cuda.synchronize()
@@ -225,6 +275,7 @@ def main():
     def step():
         for xb, yb in blocks:                         # 16 distinct blocks: nothing is re-read from the Infinity Cache
             q.execute_dev(xb, nframes, yb)
+        q.join()                                      # pipelined calls: the launch stream waits for the step's blocks
 
     # clock pre-conditioning (untimed, not part of the W warmup steps): keep the device busy with the same
     # kernel until the DVFS governor has ramped up from idle
@@ -253,6 +304,41 @@ def main():
                          device=dev if args.dist_backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
+
+    # N > 1: the one path with a real exchange step (C5: firpfbch2 sub-bands sharded over the ranks, RCCL all-gather,
+    # SURVEY 8e) rides along as an untimed extra so the scaling run measures it on real xGMI; `value` is unaffected.
+    # It runs HERE, before rank 0's single-rank extras, so no rank waits in a collective while rank 0 is busy elsewhere.
+    # A watchdog (armed behind a barrier every rank has reached) ends a collective that never completes: rank 0 still
+    # prints the headline line, and every rank leaves with a NON-ZERO code so the driver records the hang.
+    c5_result = None
+    if world > 1 and not args.no_extras:
+        import copy
+
+        def bail():
+            if rank == 0:
+                step_s = dev_ms / 1e3 / args.steps
+                print(json.dumps({"metric": "Msamples/sec, 256-tap firfilt_crcf + 4096-pt FFT stream",
+                                  "value": round(ntot * world / step_s / 1e6, 3), "unit": "Msamples/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                  "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                  "config": {"workload": "C2 stream (see the complete line of an N = 1 run)"},
+                                  "c5_sharded": {"error": "no result within 180 s (watchdog); every rank exits with "
+                                                          "code 3"}}), flush=True)
+            os._exit(3)
+
+        barrier()
+        dog = threading.Timer(180.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            import bench_c5
+            a5 = copy.copy(args)
+            a5.steps, a5.warmup, a5.prewarm_ms = min(args.steps, 5), 2, 0.0
+            c5_result = bench_c5.run(a5, rank, world, dev)
+        except Exception as e:                       # reported, never fatal for the headline line
+            c5_result = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
 
     # in-run parity spot check (rank 0): last frame of the last block vs the oracle (f64 FIR + f64 FFT)
     # on the same input; its 255-sample halo is the preceding samples of the stream
@@ -285,6 +371,23 @@ def main():
                     "the round-1 headline; NOT the value of this line",
             "ms_per_block": round(r_ms, 4), "value": round(n / r_ms / 1e3, 1), "unit": "Msamples/s",
             "frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n / r_ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+        # (1b) PCIe-inclusive rate of the headline (never `value`): the host-pointer entry point moves one 2^24-sample
+        # block H2D, runs the same kernel, and moves the spectra D2H (pageable numpy buffers)
+        try:
+            xh = x[:n].cpu().numpy()
+            qr.execute(xh)
+            t_p = time.perf_counter()
+            for _ in range(3):
+                qr.execute(xh)
+            p_ms = (time.perf_counter() - t_p) / 3 * 1e3
+            extras["pcie_inclusive"] = {
+                "what": "yagi_hip_firfft_crcf_execute on host buffers: H2D 128 MiB + kernel + D2H 128 MiB per "
+                        "2^24-sample block, wall clock; NOT the value of this line",
+                "ms_per_block": round(p_ms, 3), "value": round(n / p_ms / 1e3, 1), "unit": "Msamples/s",
+                "pcie_GBps": round(16 * n / p_ms / 1e6, 2)}
+        except Exception as e:
+            extras["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
 
         # (2) the same stream through the other algorithms
         def time_variant(v):
@@ -341,6 +444,48 @@ def main():
                 for xb, yb in blocks:
                     qf.execute_block_dev(xb, n, yb)
             leg(kname, run, ntot, 16, note, flop_per_unit=4 * TAPS if kern == 0 else None)
+        # C1 (BASELINE configs[0], the reference's own CPU-runnable case): firfilt_rrrf 63 taps over 1 M real samples.
+        # GPU: ONE execute_block_dev call on device-resident data (launch-bound at this size), and the host-pointer
+        # call (H2D + kernel + D2H); CPU: the oracle's FirFilter::execute_block on the same samples, one thread.
+        try:
+            from oracle import oracle
+            n1 = 1 << 20
+            h1 = ya.fir_design_kaiser(63, 0.2, 60.0)
+            x1h = oracle.gen_real(SEED - 2, n1)
+            x1 = torch.from_numpy(x1h).to(dev)
+            y1 = torch.empty_like(x1)
+            q1 = ya.FirFilter("rrrf", h1)
+            q1.set_scale(0.4)
+            q1.set_stream(stream.cuda_stream)
+            f1 = lambda: q1.execute_block_dev(x1.data_ptr(), n1, y1.data_ptr())
+            f1()
+            g_ms = timed(f1, 50, stream)
+            torch.cuda.synchronize()
+            q1.execute_block(x1h)
+            t_h = time.perf_counter()
+            for _ in range(5):
+                q1.execute_block(x1h)
+            host_ms = (time.perf_counter() - t_h) / 5 * 1e3
+            o1 = oracle.FirFilter("rrrf", oracle.fir_design_kaiser(63, 0.2, 60.0))
+            o1.set_scale(0.4)
+            o1.execute_block(x1h[:1 << 16])
+            t_c = time.perf_counter()
+            want = o1.execute_block(x1h)
+            cpu_ms = (time.perf_counter() - t_c) * 1e3
+            del want
+            cfg["C1_firfilt_rrrf_63"] = {
+                "units": n1, "what": "firfilt_rrrf kaiser(63, 0.2, 60 dB) scale 0.4 over 2^20 real f32 samples, one block",
+                "gpu_ms_device_resident": round(g_ms, 5), "gpu_Gunits_per_s": round(n1 / g_ms / 1e6, 2),
+                "gpu_note": "one yagi_hip_firfilt_rrrf_execute_block_dev call, launch-to-launch on the stream "
+                            "(launch-bound: the block holds 8 MiB)",
+                "gpu_ms_host_pointers": round(host_ms, 4),
+                "gpu_host_note": "yagi_hip_firfilt_rrrf_execute_block from pageable numpy buffers (H2D + kernel + D2H, "
+                                 "PCIe-inclusive wall time)",
+                "cpu_oracle_ms": round(cpu_ms, 3), "cpu_Munits_per_s": round(n1 / cpu_ms / 1e3, 2),
+                "cpu_note": "oracle/yagi_oracle.c FirFilter::execute_block (firfilt.rs:267-278, sequential sums), "
+                            "one thread, gcc -O2 no fast-math"}
+        except Exception as e:
+            cfg["C1_firfilt_rrrf_63"] = {"error": f"{type(e).__name__}: {e}"}
         plan = ya.Fft(NFFT, ya.Direction.Forward)
         nt = ntot // NFFT
         leg("C3_fft4096_batch", lambda: plan.run_batch_dev(xp, yp, nt, stream.cuda_stream), ntot, 16,
@@ -419,6 +564,9 @@ def main():
                        "samples_per_step_per_gpu": ntot, "blocks_per_step": nb, "samples_per_block": n,
                        "frames_per_block": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
+                       "block_calls": "pipelined (set_pipeline: consecutive execute_dev calls alternate between two "
+                                      "streams of the object, joined into the launch stream once per step)"
+                                      if pipelined else "plain (one stream)",
                        "kernel": kernel_name, "variant": args.variant, "prewarm_ms": args.prewarm_ms},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -439,42 +587,13 @@ def main():
             "parity_rel_l2_vs_f64": parity,
         }
         out.update(extras)
-    # N > 1: the one path with a real exchange step (C5: firpfbch2 sub-bands sharded over the ranks, RCCL all-gather,
-    # SURVEY 8e) rides along as an untimed extra so the scaling run measures it on real xGMI; `value` above is unaffected.
-    # A watchdog prints the main line and leaves if the leg does not come back (a collective that never completes).
-    if world > 1 and not args.no_extras:
-        import copy
-        import threading
-        main_line = json.dumps(out) if rank == 0 else None
-
-        def bail():
-            if rank == 0:
-                o = json.loads(main_line)
-                o["c5_sharded"] = {"error": "no result within 180 s (watchdog)"}
-                print(json.dumps(o), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(180.0, bail)
-        dog.daemon = True
-        dog.start()
-        c5 = None
-        try:
-            x = y = None                             # 4 GiB back before the C5 buffers are made
-            torch.cuda.empty_cache()
-            import bench_c5
-            a5 = copy.copy(args)
-            a5.steps, a5.warmup, a5.prewarm_ms = min(args.steps, 5), 2, 0.0
-            c5 = bench_c5.run(a5, rank, world, dev)
-        except Exception as e:                       # reported, never fatal for the headline line
-            c5 = {"error": f"{type(e).__name__}: {e}"}
-        dog.cancel()
-        if rank == 0:
-            out["c5_sharded"] = c5
+    if rank == 0 and c5_result is not None:
+        out["c5_sharded"] = c5_result
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             out["cpu_baseline"] = cpu_baseline(oracle.fir_design_kaiser(TAPS, 0.2, 60.0), scale,
-                                               threads=args.cpu_threads)
+                                               threads=args.cpu_threads or None)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

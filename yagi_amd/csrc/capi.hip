@@ -146,7 +146,7 @@ struct FirFilt {
     DevBuf apack;              // crcf only, L <= 256: Toeplitz A-operand table of the MFMA kernel
     int Lm = 0;                // padded length of the MFMA form (0 = not available)
     DevBuf hfreq, twf, twb;    // crcf only, L <= 2049: FFT_4096{[h;0]} and both twiddle tables (fast convolution)
-    DevBuf gcorr;              // crcf only, L <= 257: reversed taps of the frame-boundary correction (firfft variant 4)
+    DevBuf gfft, gfft_s;       // crcf only, L <= 257: conj(DFT_512{reversed taps}) / 512 and its scaled copy (fast correction sum)
     DevBuf hfreq_s;            // scale * hfreq for the frequency-domain stream kernel, rebuilt when the scale changes
     bool hfreq_s_valid = false;
     float hfreq_s_scale = 0.f;
@@ -556,12 +556,23 @@ int FirFilt<K>::prepare_conv() {
         }
         YG_TRY(hfreq.alloc(4096 * sizeof(cf32)));
         YG_TRY(upload(hfreq.p, hp.data(), 4096 * sizeof(cf32), st));
-        // reversed taps of the frame-boundary correction (stream_kernels.hip, firfft_crcf_4096_freq_kernel)
+        // reversed taps g[j] = h[L-1-j] of the frame-boundary correction (freq_kernels.hip)
         if (K::id == 1 && L <= 257) {
             std::vector<float> g(256, 0.0f);
             for (int j = 0; j < L - 1; ++j) g[j] = hf[L - 1 - j];
-            YG_TRY(gcorr.alloc(256 * sizeof(float)));
-            YG_TRY(upload(gcorr.p, g.data(), 256 * sizeof(float), st));
+            // the correction sum as a 512-point circular correlation: conj(DFT_512{g}) / 512 (freq_kernels.hip)
+            std::vector<cf32> gf(512);
+            for (int k = 0; k < 512; ++k) {
+                double re = 0.0, im = 0.0;
+                for (int j = 0; j < L - 1; ++j) {
+                    const double a = -2.0 * M_PI * (double)((j * k) & 511) / 512.0;
+                    re += (double)g[j] * std::cos(a);
+                    im += (double)g[j] * std::sin(a);
+                }
+                gf[k] = cf32{(float)(re / 512.0), (float)(-im / 512.0)};
+            }
+            YG_TRY(gfft.alloc(512 * sizeof(cf32)));
+            YG_TRY(upload(gfft.p, gf.data(), 512 * sizeof(cf32), st));
         }
         YG_HIP(hipStreamSynchronize(st));      // the host vectors go out of scope
     }
@@ -2262,8 +2273,8 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         YG_HIP(hipEventRecord(p.in, f.st));
         YG_HIP(hipStreamWaitEvent(p.lane[i], p.in, 0));
         YG_TRY(launch_firfft_crcf_4096_freq(p.prev_tail ? p.prev_tail : f.w.dev(), x, f.hfreq_s.as<cf32>(),
-                                            f.gcorr.as<float>(), f.scale, f.L, q->tw.as<cf32>(), spectra, nullptr,
-                                            nframes, p.lane[i]));
+                                            f.gfft_s.as<cf32>(), f.L, q->tw.as<cf32>(), spectra, nullptr, nframes,
+                                            p.lane[i]));
         YG_HIP(hipEventRecord(p.done[i], p.lane[i]));
         p.busy[i] = true;
         ++p.calls;
@@ -2276,10 +2287,12 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         if (!f.hfreq_s_valid || f.hfreq_s_scale != f.scale) {
             YG_TRY(f.hfreq_s.ensure(4096 * sizeof(cf32)));
             YG_TRY(launch_scale_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), 4096, f.st));
+            YG_TRY(f.gfft_s.ensure(512 * sizeof(cf32)));
+            YG_TRY(launch_scale_cf32(f.gfft.as<cf32>(), f.scale, f.gfft_s.as<cf32>(), 512, f.st));
             f.hfreq_s_valid = true;
             f.hfreq_s_scale = f.scale;
         }
-        YG_TRY(launch_firfft_crcf_4096_freq(f.w.dev(), x, f.hfreq_s.as<cf32>(), f.gcorr.as<float>(), f.scale, f.L,
+        YG_TRY(launch_firfft_crcf_4096_freq(f.w.dev(), x, f.hfreq_s.as<cf32>(), f.gfft_s.as<cf32>(), f.L,
                                             q->tw.as<cf32>(), spectra, f.w.next(), nframes, f.st));
         f.w.flip();
         return YAGI_OK;

@@ -145,6 +145,29 @@ __device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff
     const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
 }
+// the same with a cache-policy operand (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Data a kernel streams through exactly once
+// should neither evict the tables the resident workgroups re-read from L1 nor be kept in L2 / the Infinity Cache behind
+// the store: loads sc1 (L1 bypassed), stores nt.  Measured on the headline stream (freq_kernels.hip): -7 % together.
+// (-DYG_STREAM_LD= / -DYG_STREAM_ST= build the A/B variants of tools/ab_pkg.py.)
+#ifndef YG_STREAM_LD
+#define YG_STREAM_LD 16
+#endif
+#ifndef YG_STREAM_ST
+#define YG_STREAM_ST 2
+#endif
+constexpr int kStreamLoad = YG_STREAM_LD, kStreamStore = YG_STREAM_ST;
+template <int AUX>
+__device__ __forceinline__ float2 buf_ld_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
+    return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_st_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
+    v2u_t q;
+    q.x = __float_as_uint(v.x);
+    q.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, AUX);
+}
 template <class T>
 __device__ __forceinline__ T buf_ld_t(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (sizeof(T) == 4) {

@@ -103,11 +103,11 @@ int launch_fir_rrrf_fftconv(const float *win, const float *x, size_t pre, size_t
                             hipStream_t st, float *win_next = nullptr);
 
 // frequency-domain form of the firfilt_crcf -> 4096-pt FFT stream (1 <= L <= 257): FFT{h}.FFT{x_f} + FFT{boundary
-// correction}; hs_scaled = scale * FFT{h}; gcorr[j] = h[L-1-j] (j < L-1, zero-padded to 256 floats); tw_stream = the
+// correction}; hs_scaled = scale * FFT{h}; gfft_scaled = scale * conj(DFT_512{g}) / 512, g[j] = h[L-1-j]; tw_stream = the
 // table of make_stream_twiddles (capi.hip); win_next <- last L samples of x.
-int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs_scaled, const float *gcorr,
-                                 float scale, int L, const cf32 *tw_stream, cf32 *spectra, cf32 *win_next,
-                                 size_t nframes, hipStream_t st);
+int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs_scaled, const cf32 *gfft_scaled,
+                                 int L, const cf32 *tw_stream, cf32 *spectra, cf32 *win_next, size_t nframes,
+                                 hipStream_t st);
 
 int launch_scale_cf32(const cf32 *src, float s, cf32 *dst, size_t n, hipStream_t st);
 
