@@ -477,7 +477,7 @@ def main():
                 "units": n1, "what": "firfilt_rrrf kaiser(63, 0.2, 60 dB) scale 0.4 over 2^20 real f32 samples, one block",
                 "gpu_ms_device_resident": round(g_ms, 5), "gpu_Gunits_per_s": round(n1 / g_ms / 1e6, 2),
                 "gpu_note": "one yagi_hip_firfilt_rrrf_execute_block_dev call, launch-to-launch on the stream "
-                            "(launch-bound: the block holds 8 MiB)",
+                            "(4 MiB in + 4 MiB out, re-run in place: Infinity-Cache resident)",
                 "gpu_ms_host_pointers": round(host_ms, 4),
                 "gpu_host_note": "yagi_hip_firfilt_rrrf_execute_block from pageable numpy buffers (H2D + kernel + D2H, "
                                  "PCIe-inclusive wall time)",

@@ -330,7 +330,9 @@ YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
  *                            h1[i] = h[4m - 1 - 2i] :66-70, two 2m-sample windows, toggle -- is reproduced.
  *   create_kaiser(m, f0, as) the reference's signature with a Kaiser-windowed half-band prototype (kaiser(4m+1, 0.25, as))
  *   clone / reset / set_scale / get_scale / get_delay (= 2m - 1)                     :25,90-106
- *   execute_block[_dev](mode, x, nx, y): nx input samples through one of the five forms, state carried across calls
+ *   execute_block[_dev](mode, x, nx, y, ny): nx input samples through one of the five forms, state carried across calls;
+ *       ny = the length of y and must be the form's output count (YAGI_ERR_CONFIG otherwise: the reference's slices
+ *       carry their lengths)
  *       mode 0 filter_execute       :108-130  nx samples  -> 2 nx outputs, (y0, y1) = (low, high) per sample
  *       mode 1 analyzer_execute     :132-143  nx/2 pairs  -> nx outputs,   (low, high) per pair
  *       mode 2 synthesizer_execute  :145-157  nx/2 pairs (low, high) -> nx outputs
@@ -341,7 +343,8 @@ YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
  *                            estimate_req_filter_len, m = max(3, ceil((h_len - 1) / 4)), as + 5 dB)
  *   msresamp2 create_taps(interp, num_stages, m_stage, hf_all)  the same from externally designed stage prototypes
  *                            (hf_all = the stages' hf[4 m_s + 1] one after the other)
- *   msresamp2 execute_block[_dev](x, n, y)  n times execute() :137-152: interp n -> n 2^S, decim n 2^S -> n (x 1/2^S)
+ *   msresamp2 execute_block[_dev](x, nx, y, ny)  n times execute() :137-152: interp nx = n -> ny = n 2^S, decim
+ *                            nx = n 2^S -> ny = n (x 1/2^S); any other pair of lengths is YAGI_ERR_CONFIG (:181)
  *   msresamp2 get_params     get_type / get_num_stages / get_delay :95-135 (+ the stage semi-lengths) */
 #define YAGI_RESAMP2_API(K, T, C)                                                                   \
     typedef struct yagi_hip_resamp2_##K##_s *yagi_hip_resamp2_##K;                                  \
@@ -356,9 +359,9 @@ YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
     int yagi_hip_resamp2_##K##_get_scale(yagi_hip_resamp2_##K q, C *scale);                         \
     int yagi_hip_resamp2_##K##_get_delay(yagi_hip_resamp2_##K q, size_t *delay);                    \
     int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x,          \
-                                             size_t nx, T *y);                                      \
+                                             size_t nx, T *y, size_t ny);                           \
     int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x_dev,  \
-                                                 size_t nx, T *y_dev);                              \
+                                                 size_t nx, T *y_dev, size_t ny);                   \
     int yagi_hip_msresamp2_##K##_create(int interp, size_t num_stages, float fc, float f0,          \
                                         float as_, yagi_hip_msresamp2_##K *q);                      \
     int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
@@ -369,10 +372,10 @@ YAGI_RRESAMP_API(cccf, yagi_cf32, yagi_cf32)
     int yagi_hip_msresamp2_##K##_set_stream(yagi_hip_msresamp2_##K q, yagi_stream_t s);             \
     int yagi_hip_msresamp2_##K##_get_params(yagi_hip_msresamp2_##K q, int *interp,                  \
                                             size_t *num_stages, float *delay, size_t *m_stage);     \
-    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n,      \
-                                               T *y);                                               \
+    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t nx,     \
+                                               T *y, size_t ny);                                    \
     int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x_dev,        \
-                                                   size_t n, T *y_dev);
+                                                   size_t nx, T *y_dev, size_t ny);
 
 YAGI_RESAMP2_API(rrrf, float, float)
 YAGI_RESAMP2_API(crcf, yagi_cf32, float)

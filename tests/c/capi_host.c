@@ -2,7 +2,9 @@
  * C ABI exactly as INTEGRATION.md section 2 shows.  Prints values that tests/test_gpu_chost.py compares with the
  * Python mirror's results on the same generated input.
  *   cc capi_host.c -I../../include -L../../yagi_amd -lyagi_hip -Wl,-rpath,<repo>/yagi_amd -lm -o capi_host */
+#define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <math.h>
 #include "yagi_hip.h"
@@ -56,6 +58,23 @@ int main(void) {
     size_t len = 0;
     CHECK(yagi_hip_firfilt_crcf_get_length(q, &len));
     printf("fir_len %zu\n", len);
+    /* per-sample calls after a block call: served from the host mirror of the window (one download, then no launches) */
+    {
+        enum { NPS = 200000 };
+        yagi_cf32 xs = {0.25f, -0.5f}, ys = {0.0f, 0.0f}, acc = {0.0f, 0.0f};
+        struct timespec t0, t1;
+        CHECK(yagi_hip_firfilt_crcf_execute_one(q, xs, &ys));          /* pays the one device -> host window copy */
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < NPS; i++) {
+            xs.re = (float)(i & 7) * 0.125f;
+            CHECK(yagi_hip_firfilt_crcf_execute_one(q, xs, &ys));
+            acc.re += ys.re;
+            acc.im += ys.im;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("per_sample_ns %.1f\n", ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / NPS);
+        printf("per_sample_acc %.6e %.6e\n", (double)acc.re, (double)acc.im);
+    }
     CHECK(yagi_hip_firfilt_crcf_destroy(q));
 
     /* error path: message available through yagi_hip_last_error() */

@@ -271,16 +271,20 @@ def test_config_c2_firfilt_crcf_256tap_stream(ya, oracle):
 # ---------------------------------------------------------------------------------- firdecim
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("case,M", [("m2h4x20", 2), ("m3h7x30", 3), ("m4h13x40", 4), ("m5h23x50", 5)])
-def test_firdecim_golden(ya, kind, case, M):
-    """firdecim.rs:295-473, epsilon 1e-3; firdecim_block (:246-279): block == per call"""
+def test_firdecim_golden(ya, oracle, kind, case, M):
+    """firdecim.rs:295-473, epsilon 1e-3; firdecim_block (:246-279): block == per call.  The per-call form runs on the
+    host mirror with the reference's sequential sums (bitwise the oracle's), the block form on the device (fused
+    multiply-adds: equal to f32 rounding)"""
     g = load_golden("firdecim")
     h, x, y = (g[f"firdecim_{kind}_data_{case}_{s}"] for s in "hxy")
     q = ya.FirDecimationFilter(kind, M, h)
     got = q.execute_block(x, len(y))
     np.testing.assert_allclose(got, y, atol=1e-3, rtol=0)
-    q2 = ya.FirDecimationFilter(kind, M, h)
-    per = np.array([q2.execute(x[i * M:(i + 1) * M]) for i in range(len(y))])
-    assert np.array_equal(per, got)
+    q2, ref = ya.FirDecimationFilter(kind, M, h), oracle.FirDecimationFilter(kind, M, h)
+    per = np.array([q2.execute(x[i * M:(i + 1) * M]) for i in range(len(y))]).astype(got.dtype)
+    want = np.array([ref.execute(x[i * M:(i + 1) * M]) for i in range(len(y))]).astype(got.dtype)
+    assert per.tobytes() == want.tobytes()
+    np.testing.assert_allclose(per, got, atol=2e-6, rtol=1e-5)
     assert q.get_decim_rate() == M
 
 
@@ -606,3 +610,92 @@ def test_device_pointers_of_any_alignment(ya, oracle, kind):
     d.execute_block_dev(dx.ptr + isz, n, dy.ptr + isz)
     ya.synchronize()
     assert np.array_equal(dy.to_numpy(n, offset=1), ref)
+
+
+# ---------------------------------------------------------------------------------- per-sample calls on the host mirror
+@pytest.mark.parametrize("kind", KINDS)
+def test_per_sample_calls_interleaved_with_blocks(ya, oracle, kind):
+    """push() / execute() / execute_one() are served from a host mirror of the window with the
+    reference's own sequential sums (firfilt.rs:220-261), synchronised lazily with the device window when a block call
+    follows (and back after one).  Integer data: every output of an arbitrary interleaving equals the oracle's bit for bit.
+    Random data: the per-sample outputs are BITWISE the oracle's (same products, same order, same two-slice split of the
+    VecDeque, whose ring position the block calls advance too); the block outputs within the f32 bound."""
+    rng = np.random.default_rng(314)
+    for L in (5, 64, 256):
+        for integer in (True, False):
+            h = int_taps(rng, kind, L) if integer else rand_taps(rng, kind, L)
+            x = int_samples(rng, kind, 3000) if integer else rand_samples(rng, kind, 3000)
+            ref, q = oracle.FirFilter(kind, h), ya.FirFilter(kind, h)
+            if not integer:
+                ref.set_scale(0.4 if kind != "cccf" else 0.4 - 0.25j)
+                q.set_scale(0.4 if kind != "cccf" else 0.4 - 0.25j)
+            want = ref.execute_block(x)
+            got = np.empty_like(x)
+            per_sample = np.zeros(x.size, bool)
+            i = 0
+            plan = [("one", 3), ("block", 700), ("push", 11), ("block", 1), ("one", L + 3), ("block", 513), ("write", 40),
+                    ("one", 1), ("block", 900)]
+            for what, n in plan:
+                n = min(n, x.size - i)
+                if what == "block":
+                    got[i:i + n] = q.execute_block(x[i:i + n])
+                elif what == "one":
+                    for k in range(i, i + n):
+                        got[k] = q.execute_one(x[k])
+                    per_sample[i:i + n] = True
+                elif what == "push":
+                    for k in range(i, i + n):
+                        q.push(x[k])
+                        got[k] = q.execute()
+                    per_sample[i:i + n] = True
+                else:                                     # write(): pushes only; the output after the last one
+                    q.write(x[i:i + n])
+                    got[i:i + n - 1] = want[i:i + n - 1]
+                    got[i + n - 1] = q.execute()
+                    per_sample[i + n - 1] = True
+                i += n
+            rest = slice(i, x.size)
+            got[rest] = q.execute_block(x[rest])
+            if integer:
+                assert np.array_equal(got, want), (kind, L)
+            else:
+                assert np.array_equal(got[per_sample].view(np.uint32), want[per_sample].view(np.uint32)), (kind, L)
+                truth = oracle.fir_block_f64(kind, h, x, scale=ref_scale(kind))
+                assert np.max(np.abs(got - truth)) <= fir_bound(kind, h, x)
+
+
+def ref_scale(kind):
+    return 0.4 if kind != "cccf" else 0.4 - 0.25j
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_per_sample_firpfb_and_firdecim_on_the_host_mirror(ya, oracle, kind):
+    """FirPfbFilter::push / execute(i) (firpfb.rs:255-286) and FirDecimationFilter::execute (firdecim.rs:179-191) per call:
+    bitwise the oracle's sequential sums, interleaved with block calls that move the window on the device"""
+    rng = np.random.default_rng(2718)
+    nf, hs = 6, 9
+    h = rand_taps(rng, kind, nf * hs + 2)                 # h_len % nf != 0: the floor of firpfb.rs:42
+    x = rand_samples(rng, kind, 400)
+    ref, q = oracle.FirPfbFilter(kind, nf, h), ya.FirPfbFilter(kind, nf, h)
+    for k in range(60):
+        ref.push(x[k]); q.push(x[k])
+        a, b = ref.execute(k % nf), q.execute(k % nf)
+        assert np.array([a]).astype(x.dtype).tobytes() == np.array([b]).astype(x.dtype).tobytes(), k
+    blk_ref, blk = ref.execute_block(2, x[60:300]), q.execute_block(2, x[60:300])      # device block: f32 bound
+    assert np.max(np.abs(blk - blk_ref)) <= 1e-5
+    for k in range(300, 330):
+        ref.push(x[k]); q.push(x[k])
+        a, b = ref.execute(5), q.execute(5)
+        assert np.array([a]).astype(x.dtype).tobytes() == np.array([b]).astype(x.dtype).tobytes(), k
+    M, L = 4, 23
+    hd = rand_taps(rng, kind, L)
+    rd, qd = oracle.FirDecimationFilter(kind, M, hd), ya.FirDecimationFilter(kind, M, hd)
+    for k in range(0, 80, M):
+        a, b = rd.execute(x[k:k + M]), qd.execute(x[k:k + M])
+        assert np.array([a]).astype(x.dtype).tobytes() == np.array([b]).astype(x.dtype).tobytes(), k
+    yb_ref, yb = rd.execute_block(x[80:280], 50), qd.execute_block(x[80:280], 50)
+    assert np.max(np.abs(yb - yb_ref)) <= 1e-5
+    a, b = rd.execute(x[280:284]), qd.execute(x[280:284])
+    assert np.array([a]).astype(x.dtype).tobytes() == np.array([b]).astype(x.dtype).tobytes()
+    with pytest.raises(ya.ConfigError):
+        qd.execute(x[:M - 1])                            # firdecim.rs:182 indexes x[i] for i < M

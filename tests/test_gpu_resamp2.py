@@ -310,3 +310,38 @@ def test_device_entry_points_reject_overlapping_buffers(ya):
     with pytest.raises(ya.ConfigError):
         r.execute_block_dev(ya.Resamp2.INTERP, buf.ptr, n, buf.ptr + 8 * (n - 1))
     ya.synchronize()
+
+
+@pytest.mark.parametrize("kind", ["rrrf", "crcf", "cccf"])
+def test_resamp2_length_mismatch_is_a_config_error(ya, kind):
+    """the resamp2 / msresamp2 block entry points carry both buffer lengths (the reference's slices do:
+    msresamp2.rs:181 copy_from_slice panics on a mismatch); a wrong pair is YAGI_ERR_CONFIG and nothing is read or
+    written, host and device forms alike, with the object's state untouched"""
+    T = np.float32 if kind == "rrrf" else np.complex64
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(64) + (0 if kind == "rrrf" else 1j * rng.standard_normal(64))).astype(T)
+    md, md2 = (ya.MsResamp2(kind, ya.MsResamp2.DECIM, 2, 0.4, 0.0, 60.0) for _ in range(2))
+    mi = ya.MsResamp2(kind, ya.MsResamp2.INTERP, 2, 0.4, 0.0, 60.0)
+    with pytest.raises(ya.ConfigError):
+        md.execute_block(x[:30], 8)                   # 8 outputs of a /4 decimator need 32 inputs
+    with pytest.raises(ya.ConfigError):
+        md.execute_block(x[:33], 8)
+    with pytest.raises(ya.ConfigError):
+        mi.execute_block(x[:7], 8)                    # 8 calls of an interpolator need 8 inputs
+    assert np.array_equal(md.execute_block(x[:32], 8), md2.execute_block(x[:32], 8))    # state untouched by the refusals
+    dx = ya.DeviceArray.from_numpy(x)
+    dy = ya.DeviceArray(256, T)
+    with pytest.raises(ya.ConfigError):
+        md.execute_block_dev(dx, 8, dy, nx=31)
+    with pytest.raises(ya.ConfigError):
+        mi.execute_block_dev(dx, 8, dy, ny=31)
+    r = ya.Resamp2.new(kind, 5, 0.0, 60.0)
+    lib_fn = r._fn("execute_block")
+    y = np.zeros(256, T)
+    from yagi_amd import _ptr
+    for mode, nx, ny in ((ya.Resamp2.FILTER, 8, 8), (ya.Resamp2.DECIM, 8, 8), (ya.Resamp2.INTERP, 8, 8),
+                         (ya.Resamp2.ANALYZER, 8, 16), (ya.Resamp2.SYNTHESIZER, 8, 4), (ya.Resamp2.DECIM, 7, 3)):
+        assert lib_fn(r._h, mode, _ptr(x), nx, _ptr(y), ny) == 2, (mode, nx, ny)      # YAGI_ERR_CONFIG
+        with pytest.raises(ya.ConfigError):
+            r.execute_block_dev(mode, dx, nx, dy, ny)
+    assert not y.any()

@@ -637,11 +637,13 @@ class Resamp2(_FirBase):
     def execute_block(self, mode, x):
         x = _arr(x, self.T)
         y = np.empty(self._out_count(mode, x.size), self.T)
-        _check(self._fn("execute_block")(self._h, mode, _ptr(x), x.size, _ptr(y)))
+        _check(self._fn("execute_block")(self._h, mode, _ptr(x), x.size, _ptr(y), y.size))
         return y
 
-    def execute_block_dev(self, mode, x_dev, nx, y_dev):
-        _check(self._fn("execute_block_dev")(self._h, mode, _devptr(x_dev), nx, _devptr(y_dev)))
+    def execute_block_dev(self, mode, x_dev, nx, y_dev, ny=None):
+        """ny = samples the output buffer holds (default: what the form produces from nx)"""
+        ny = self._out_count(mode, nx) if ny is None else ny
+        _check(self._fn("execute_block_dev")(self._h, mode, _devptr(x_dev), nx, _devptr(y_dev), ny))
 
     # the reference's per-call forms
     def filter_execute(self, x):                              # :108-130 -> (y0, y1)
@@ -705,17 +707,23 @@ class MsResamp2(_FirBase):
     get_scale = set_scale
 
     def execute_block(self, x, n=None):
-        """n execute() calls (:137-152): interp: n inputs -> n*rate outputs; decim: n*rate inputs -> n outputs"""
+        """n execute() calls (:137-152): interp: n inputs -> n*rate outputs; decim: n*rate inputs -> n outputs.
+        x must hold exactly the n calls' input (the reference's copy_from_slice panics otherwise, :181)"""
         x = _arr(x, self.T)
         it, ns, _, _ = self._params()
         rate = 1 << ns
         n = (x.size if it else x.size // rate) if n is None else n
         y = np.empty(n * rate if it else n, self.T)
-        _check(self._fn("execute_block")(self._h, _ptr(x), n, _ptr(y)))
+        _check(self._fn("execute_block")(self._h, _ptr(x), x.size, _ptr(y), y.size))
         return y
 
-    def execute_block_dev(self, x_dev, n, y_dev):
-        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
+    def execute_block_dev(self, x_dev, n, y_dev, nx=None, ny=None):
+        """n execute() calls on device buffers of nx / ny samples (defaults: exactly what n calls consume / produce)"""
+        it, ns, _, _ = self._params()
+        rate = 1 << ns
+        nx = (n if it else n * rate) if nx is None else nx
+        ny = (n * rate if it else n) if ny is None else ny
+        _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), nx, _devptr(y_dev), ny))
 
     def execute(self, x):                                     # :137-152
         return self.execute_block(x, 1)

@@ -259,8 +259,8 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "set_scale", vp, _Cc)
     _sig(p + "get_scale", vp, vp)
     _sig(p + "get_delay", vp, C.POINTER(sz))
-    _sig(p + "execute_block", vp, ci, vp, sz, vp)
-    _sig(p + "execute_block_dev", vp, ci, vp, sz, vp)
+    _sig(p + "execute_block", vp, ci, vp, sz, vp, sz)
+    _sig(p + "execute_block_dev", vp, ci, vp, sz, vp, sz)
     p = f"yagi_hip_msresamp2_{_k}_"
     _sig(p + "create", ci, sz, f32, f32, f32, pvp)
     _sig(p + "create_taps", ci, sz, vp, vp, pvp)
@@ -269,5 +269,5 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "reset", vp)
     _sig(p + "set_stream", vp, vp)
     _sig(p + "get_params", vp, C.POINTER(ci), C.POINTER(sz), C.POINTER(f32), vp)
-    _sig(p + "execute_block", vp, vp, sz, vp)
-    _sig(p + "execute_block_dev", vp, vp, sz, vp)
+    _sig(p + "execute_block", vp, vp, sz, vp, sz)
+    _sig(p + "execute_block_dev", vp, vp, sz, vp, sz)

@@ -4,11 +4,12 @@
 //
 // State model.  The reference keeps a Window<T>/VecDeque<T> of the last L samples inside each
 // object (firfilt.rs:13, firdecim.rs:15, firpfb.rs:12).  Here that window lives in HBM as L
-// samples, oldest first (ping-pong pair so an update never races the kernel reading it).
-// Per-sample push() only queues the sample on the host; the queue is flushed into the device
-// window (one small kernel) before anything reads the state.  Per-sample execute() is the
-// standalone dotprod kernel over (window, taps); block calls run the FIR kernels and then
-// advance the window.  clone() copies the device state; reset() zeroes it.
+// samples, oldest first (a ring of three buffers so an update never races the kernel reading it),
+// with a host mirror for the per-sample calls: push() / execute() / execute_one() run on the host
+// mirror with the reference's own sequential sums (host.cpp: tens of nanoseconds per call, no
+// launch), block calls run the FIR kernels on the device window; the two copies are synchronised
+// lazily when the caller switches between the two kinds of call (DevWindow).  clone() copies the
+// state; reset() zeroes it.
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -59,26 +60,39 @@ static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
 template <class T>
 struct DevWindow {
     int len = 0;
-    static constexpr int kBufs = 3;   // a ring of three: the pipelined stream (FirFft) writes window b+1 while block b reads window b
+    static constexpr int kBufs = 3;   // a ring of three: kernels write window b+1 into next() while block b reads dev()
     DevBuf buf[kBufs];
     int cur = 0;
-    std::vector<T> pending;
-    DevBuf stage;
+    // Host mirror for the per-sample calls (push / execute / execute_one: firfilt.rs:220-261, firpfb.rs:255-286,
+    // firdecim.rs:179-191).  hbuf[hend - len, hend) = the last len samples, oldest first -- Window<T>::read()'s layout
+    // (window.rs:77-85): a push appends, and when the slack behind the window is used up the window moves back to the
+    // front.  The two copies are synchronised lazily: a per-sample call after a block call downloads the device window
+    // once (ensure_host), a block call after per-sample calls uploads the host window once (ensure_dev); in between,
+    // per-sample calls cost a sequential dot product on the host and no launch.
+    static constexpr size_t kSlack = 4096;
+    std::vector<T> hbuf;
+    size_t hend = 0;
+    bool host_valid = true, dev_valid = true;
+    uint64_t npush = 0;               // samples pushed since the window was made: the ring position of FirFilter's VecDeque
 
     int init(int n, hipStream_t st) {
         len = n;
         for (auto &b : buf) YG_TRY(b.alloc((size_t)n * sizeof(T)));
+        hbuf.assign((size_t)n + kSlack, T{});
+        npush = 0;
         return reset(st);
     }
-    int reset(hipStream_t st) {
-        pending.clear();
+    int reset(hipStream_t st) {       // zeroes the samples in place; the ring position is kept (firfilt.rs:209-213)
         YG_HIP(hipMemsetAsync(buf[cur].p, 0, (size_t)len * sizeof(T), st));
+        std::fill(hbuf.begin(), hbuf.begin() + len, T{});
+        hend = (size_t)len;
+        host_valid = dev_valid = true;
         return YAGI_OK;
     }
     const T *dev() const { return buf[cur].template as<T>(); }
     // for kernels that write the next window themselves: the other buffer, then flip()
     T *next() { return buf[(cur + 1) % kBufs].template as<T>(); }
-    void flip() { cur = (cur + 1) % kBufs; }
+    void flip() { cur = (cur + 1) % kBufs; host_valid = false; }
     // window <- last len of (window ++ x_dev[0..n))
     int advance(const T *x_dev, size_t n, hipStream_t st) {
         if (n == 0) return YAGI_OK;
@@ -86,49 +100,51 @@ struct DevWindow {
         flip();
         return YAGI_OK;
     }
-    void push(T v) {
-        pending.push_back(v);
-        if (pending.size() > (size_t)len + 65536) pending.erase(pending.begin(), pending.end() - len);
+    const T *host() const { return hbuf.data() + (hend - (size_t)len); }        // oldest first; valid after ensure_host
+    void push(T v) {                                                              // after ensure_host
+        if (hend == hbuf.size()) {
+            std::memmove(hbuf.data(), hbuf.data() + (hend - (size_t)len + 1), ((size_t)len - 1) * sizeof(T));
+            hend = (size_t)len - 1;
+        }
+        hbuf[hend++] = v;
+        ++npush;
+        dev_valid = false;
     }
-    int flush(hipStream_t st) {
-        if (pending.empty()) return YAGI_OK;
-        // only the last `len` queued samples can still be inside the window
-        const size_t skip = pending.size() > (size_t)len ? pending.size() - len : 0;
-        const size_t n = pending.size() - skip;
-        YG_TRY(stage.ensure(n * sizeof(T)));
-        YG_TRY(upload(stage.p, pending.data() + skip, n * sizeof(T), st));
-        YG_TRY(advance(stage.template as<T>(), n, st));
+    // the device window is what the block kernels read: bring it up to date with the host mirror
+    int ensure_dev(hipStream_t st) {
+        if (dev_valid) return YAGI_OK;
+        YG_HIP(hipMemcpyAsync(buf[cur].p, host(), (size_t)len * sizeof(T), hipMemcpyHostToDevice, st));
         YG_HIP(hipStreamSynchronize(st));
-        pending.clear();
+        dev_valid = true;
         return YAGI_OK;
     }
-    int clone_from(const DevWindow &o, hipStream_t st) {
+    // the host mirror is what the per-sample calls read: fetch the window a block kernel left on the device
+    int ensure_host(hipStream_t st) {
+        if (host_valid) return YAGI_OK;
+        YG_HIP(hipMemcpyAsync(hbuf.data(), buf[cur].p, (size_t)len * sizeof(T), hipMemcpyDeviceToHost, st));
+        YG_HIP(hipStreamSynchronize(st));
+        hend = (size_t)len;
+        host_valid = true;
+        return YAGI_OK;
+    }
+    int clone_from(const DevWindow &o, hipStream_t st) {       // o.ensure_dev() has run
         YG_TRY(init(o.len, st));
         YG_HIP(hipMemcpyAsync(buf[cur].p, o.buf[o.cur].p, (size_t)len * sizeof(T), hipMemcpyDeviceToDevice, st));
         YG_HIP(hipStreamSynchronize(st));
-        pending = o.pending;
+        npush = o.npush;
+        host_valid = false;
         return YAGI_OK;
     }
 };
+
+// the per-sample arithmetic (host.cpp): the reference's own sequential sums, products unfused
+template <class T, class C> T host_fir_ring_dot(const T *w, size_t L, size_t head, const C *h, C scale);
+template <class T, class C> T host_fir_window_dot(const T *w, size_t L, const C *h, C scale);
 
 // workspaces shared by the host-pointer entry points of one object
 struct Workspace {
     DevBuf x, y, scratch;
 };
-
-// scale * sum_i win[i] * taps[L-1-i] -> host value   (execute(): firfilt.rs:241-246)
-template <class K>
-static int window_dot(const typename K::T *win, const typename K::C *taps, int L, typename K::C scale,
-                      Workspace &ws, typename K::T *y_host, hipStream_t st) {
-    using T = typename K::T;
-    using C = typename K::C;
-    const size_t np = dotprod_num_partials((size_t)L);
-    YG_TRY(ws.scratch.ensure((np + 1) * sizeof(T)));
-    T *part = ws.scratch.as<T>();
-    T *res = part + np;
-    YG_TRY((launch_dotprod<T, C, T, C>(win, taps, (size_t)L, true, scale, part, res, st)));
-    return download(y_host, res, sizeof(T), st);
-}
 
 // ---------------------------------------------------------------------------------------------
 // FirFilter<T,C>
@@ -187,6 +203,12 @@ struct FirFilt {
         return w.init(L, st);
     }
     int block_dev(const T *x, size_t n, T *y);
+    // execute() on the host mirror (firfilt.rs:241-246): the VecDeque's head moves back one slot per push, so after
+    // npush pushes it sits at (-npush) mod L and as_slices() splits the newest-first sequence L - head from its start
+    T host_execute() const {
+        const size_t Ls = (size_t)L, head = (Ls - (size_t)(w.npush % Ls)) % Ls;
+        return host_fir_ring_dot<T, C>(w.host(), Ls, head, h.data(), scale);
+    }
 };
 
 // execute_block on device data.  The auto choice is always a direct form (the dotprod sums of the reference,
@@ -194,8 +216,9 @@ struct FirFilt {
 // combination: 2.5x (crcf 256 taps) to 10x (rrrf / cccf) faster on long blocks, equal to f32 rounding.
 template <class K>
 int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
-    YG_TRY(w.flush(st));
+    YG_TRY(w.ensure_dev(st));
     if (n == 0) return YAGI_OK;
+    w.npush += n;
     const bool conv = kernel_choice == 4 && L <= 2049;
     if (conv) {
         YG_TRY(prepare_conv());
@@ -212,8 +235,9 @@ int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
 }
 template <>
 int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
-    YG_TRY(w.flush(st));
+    YG_TRY(w.ensure_dev(st));
     if (n == 0) return YAGI_OK;
+    w.npush += n;
     const bool conv = kernel_choice == 4 && L <= 2049;
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
     if (conv) {
@@ -264,7 +288,7 @@ struct FirDecim {
     }
     // n outputs from n*M device samples
     int block_dev(const T *x, size_t n, T *y) {
-        YG_TRY(w.flush(st));
+        YG_TRY(w.ensure_dev(st));
         if (n == 0) return YAGI_OK;
         YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, M, scale, y, n, st, 0, w.next())));
         w.flip();                                   // the kernel's last workgroup wrote the next window
@@ -309,7 +333,7 @@ struct FirPfb {
     }
     int block_dev(size_t i, const T *x, size_t n, T *y) {
         YG_TRY(check_branch(i));
-        YG_TRY(w.flush(st));
+        YG_TRY(w.ensure_dev(st));
         YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>() + i * (size_t)Ls, Ls, 1, scale, y, n, st)));
         return w.advance(x, n, st);
     }
@@ -943,7 +967,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
-        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY(q->w.ensure_dev(q->st));                                                                  \
         auto o = std::make_unique<yagi_hip_firfilt_##K##_s>();                                      \
         o->st = q->st;                                                                              \
         YG_TRY(o->init(q->h.data(), q->h.size()));                                                  \
@@ -975,25 +999,31 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_push(yagi_hip_firfilt_##K q, T x) try {                              \
         CHECK_Q(q);                                                                                 \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
         q->w.push(x);                                                                               \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_write(yagi_hip_firfilt_##K q, const T *x, size_t n) try {            \
         CHECK_Q(q);                                                                                 \
         if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
         for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_execute(yagi_hip_firfilt_##K q, T *y) try {                          \
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(y);                                                                               \
-        YG_TRY(q->w.flush(q->st));                                                                  \
-        return window_dot<KT>(q->w.dev(), q->taps.as<C>(), q->L, q->scale, q->ws, y, q->st);        \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
+        *y = q->host_execute();                                                                     \
+        return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_execute_one(yagi_hip_firfilt_##K q, T x, T *y) try {                 \
         CHECK_Q(q);                                                                                 \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
         q->w.push(x);                                                                               \
-        return yagi_hip_firfilt_##K##_execute(q, y);                                                \
+        *y = q->host_execute();                                                                     \
+        return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_execute_block(yagi_hip_firfilt_##K q, const T *x, size_t nx, T *y,   \
                                              size_t ny) try {                                       \
@@ -1076,7 +1106,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
-        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY(q->w.ensure_dev(q->st));                                                                  \
         auto o = std::make_unique<yagi_hip_firdecim_##K##_s>();                                     \
         o->st = q->st;                                                                              \
         YG_TRY(o->init((size_t)q->M, q->h.data(), q->h.size()));                                    \
@@ -1121,7 +1151,14 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firdecim_##K##_execute(yagi_hip_firdecim_##K q, const T *x, size_t nx, T *y) try { \
         CHECK_Q(q);                                                                                 \
-        return firdecim_block_host<KT>(q, x, nx, 1, y);                                             \
+        if (nx < (size_t)q->M) return fail(YAGI_ERR_CONFIG, "input block too short: need %zu samples, got %zu", (size_t)q->M, nx); \
+        CHECK_PTR(x);                                                                               \
+        CHECK_PTR(y);                                                                               \
+        YG_TRY(q->w.ensure_host(q->st));                       /* firdecim.rs:179-191: output after the FIRST of the M pushes */ \
+        q->w.push(x[0]);                                                                            \
+        *y = host_fir_window_dot<T, C>(q->w.host(), (size_t)q->L, q->h.data(), q->scale);           \
+        for (int i = 1; i < q->M; ++i) q->w.push(x[i]);                                             \
+        return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firdecim_##K##_execute_block(yagi_hip_firdecim_##K q, const T *x, size_t nx,       \
                                               size_t n, T *y) try {                                 \
@@ -1173,7 +1210,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
-        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY(q->w.ensure_dev(q->st));                                                                  \
         auto o = std::make_unique<yagi_hip_firpfb_##K##_s>();                                       \
         o->st = q->st;                                                                              \
         o->nf = q->nf;                                                                              \
@@ -1210,12 +1247,14 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_push(yagi_hip_firpfb_##K q, T x) try {                                \
         CHECK_Q(q);                                                                                 \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
         q->w.push(x);                                                                               \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_write(yagi_hip_firpfb_##K q, const T *x, size_t n) try {              \
         CHECK_Q(q);                                                                                 \
         if (n && !x) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
         for (size_t i = 0; i < n; ++i) q->w.push(x[i]);                                             \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
@@ -1223,9 +1262,9 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(y);                                                                               \
         YG_TRY(q->check_branch(i));                                                                 \
-        YG_TRY(q->w.flush(q->st));                                                                  \
-        return window_dot<KT>(q->w.dev(), q->taps.as<C>() + i * (size_t)q->Ls, q->Ls, q->scale,     \
-                              q->ws, y, q->st);                                                     \
+        YG_TRY(q->w.ensure_host(q->st));                                                            \
+        *y = host_fir_window_dot<T, C>(q->w.host(), (size_t)q->Ls, q->hb.data() + i * (size_t)q->Ls, q->scale); \
+        return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firpfb_##K##_execute_block(yagi_hip_firpfb_##K q, size_t i, const T *x, size_t nx, \
                                             T *y, size_t ny) try {                                  \
@@ -1247,7 +1286,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n, y, n * (size_t)q->nf);                                                  \
-        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY(q->w.ensure_dev(q->st));                                                                  \
         YG_TRY((launch_firpfb_all<KT>(q->w.dev(), x, q->taps.as<C>(), q->nf, q->Ls, q->scale, y, n, \
                                       q->st)));                                                     \
         return q->w.advance(x, n, q->st);                                                           \
@@ -1260,7 +1299,7 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         CHECK_NOALIAS(x, n, y, n);                                                                  \
-        YG_TRY(q->w.flush(q->st));                                                                  \
+        YG_TRY(q->w.ensure_dev(q->st));                                                                  \
         YG_TRY((launch_firpfb_select<KT>(q->w.dev(), x, q->taps.as<C>(), idx, q->nf, q->Ls,         \
                                          q->scale, y, n, q->st)));                                  \
         return q->w.advance(x, n, q->st);                                                           \
@@ -1381,7 +1420,7 @@ struct FirInterp {
     }
     // n inputs -> n*interp outputs (device pointers)
     int block_dev(const T *x, size_t n, T *y) {
-        YG_TRY(bank.w.flush(bank.st));
+        YG_TRY(bank.w.ensure_dev(bank.st));
         if (n == 0) return YAGI_OK;
         YG_TRY((launch_firpfb_all<K>(bank.w.dev(), x, bank.taps.template as<C>(), bank.nf, bank.Ls,
                                      bank.scale, y, n, bank.st, bank.w.next())));
@@ -1458,7 +1497,7 @@ struct FirInterp {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
-        YG_TRY(q->bank.w.flush(q->bank.st));                                                        \
+        YG_TRY(q->bank.w.ensure_dev(q->bank.st));                                                        \
         auto o = std::make_unique<yagi_hip_firinterp_##K##_s>();                                    \
         o->interp = q->interp;                                                                      \
         o->hs = q->hs;                                                                              \
@@ -1571,7 +1610,7 @@ struct RresampObj {
     }
     // nblocks primitive blocks: nblocks*Q inputs -> nblocks*P outputs (device pointers); :162-183
     int blocks_dev(const T *x, size_t nblocks, T *y) {
-        YG_TRY(bank.w.flush(bank.st));
+        YG_TRY(bank.w.ensure_dev(bank.st));
         if (nblocks == 0) return YAGI_OK;
         YG_TRY((launch_rresamp<K>(bank.w.dev(), x, bank.taps.template as<C>(), P, Q, bank.Ls, bank.scale, y,
                                   nblocks, bank.st, bank.w.next())));
@@ -1634,7 +1673,7 @@ struct RresampObj {
         CHECK_Q(q);                                                                                 \
         CHECK_PTR(out);                                                                             \
         *out = nullptr;                                                                             \
-        YG_TRY(q->bank.w.flush(q->bank.st));                                                        \
+        YG_TRY(q->bank.w.ensure_dev(q->bank.st));                                                        \
         auto o = std::make_unique<yagi_hip_rresamp_##K##_s>();                                      \
         o->bank.st = q->bank.st;                                                                    \
         o->bank.nf = q->bank.nf;                                                                    \
@@ -1683,6 +1722,7 @@ struct RresampObj {
         CHECK_Q(q);                                                                                 \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
+        YG_TRY(q->bank.w.ensure_host(q->bank.st));                                                  \
         for (size_t i = 0; i < n; ++i) q->bank.w.push(x[i]);                                        \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
@@ -2113,7 +2153,7 @@ struct FftFiltObj {
         YG_TRY(o->init(q->h.data(), q->h.size(), (size_t)q->n));                                    \
         o->scale = q->scale;                                                                        \
         if (q->use_conv) {                                                                          \
-            YG_TRY(q->fir.w.flush(q->st));                                                          \
+            YG_TRY(q->fir.w.ensure_dev(q->st));                                                          \
             YG_TRY(o->fir.w.clone_from(q->fir.w, q->st));                                           \
         } else {                                                                                    \
             YG_HIP(hipMemcpyAsync(o->w[o->cur].p, q->w[q->cur].p, (size_t)q->n * sizeof(cf32),      \
@@ -2249,10 +2289,10 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_NOALIAS(x, nframes * q->nfft, spectra, nframes * q->nfft);
     auto &f = q->fir;
     const bool use_freq = q->nfft == 4096 && (q->variant == 4 || (q->variant == 0 && f.L <= 257));
-    const bool piped = q->pipe.on && use_freq && f.w.pending.empty() && f.conv_ready && f.hfreq_s_valid &&
+    const bool piped = q->pipe.on && use_freq && f.w.dev_valid && f.conv_ready && f.hfreq_s_valid &&
                        f.hfreq_s_scale == f.scale;
     if (!piped) YG_TRY(q->join());        // everything below runs on the caller's stream
-    YG_TRY(f.w.flush(f.st));
+    YG_TRY(f.w.ensure_dev(f.st));
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
     // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
     if (q->nfft != 4096) {     // other frame lengths: overlap-save FIR into a scratch stream, then the batched transform
@@ -2658,6 +2698,16 @@ struct Resamp2Obj {
     static size_t out_count(int mode, size_t nx) {
         return mode == kR2Filter || mode == kR2Interp ? 2 * nx : mode == kR2Decim ? nx / 2 : nx;
     }
+    // the reference's slices carry their lengths (copy_from_slice / indexing panics on a mismatch); the C ABI checks
+    static int check_lengths(int mode, size_t nx, size_t ny) {
+        if (mode < kR2Filter || mode > kR2Interp) return fail(YAGI_ERR_CONFIG, "resamp2: unknown form %d", mode);
+        if (mode != kR2Filter && mode != kR2Interp && (nx & 1))
+            return fail(YAGI_ERR_CONFIG, "resamp2: this form consumes pairs of samples (got %zu)", nx);
+        if (ny != out_count(mode, nx))
+            return fail(YAGI_ERR_CONFIG, "resamp2: form %d turns %zu samples into %zu, the output holds %zu", mode, nx,
+                        out_count(mode, nx), ny);
+        return YAGI_OK;
+    }
     int block_dev(int mode, const T *x, size_t nx, T *y) {
         if (mode < kR2Filter || mode > kR2Interp) return fail(YAGI_ERR_CONFIG, "resamp2: unknown form %d", mode);
         if (mode != kR2Filter && mode != kR2Interp && (nx & 1))
@@ -2726,6 +2776,17 @@ struct MsResamp2Obj {
     std::vector<std::unique_ptr<Resamp2Obj<K>>> stage;
     DevBuf buf[2];
     Workspace ws;
+
+    // n execute() calls: interpolator n -> n * rate, decimator n * rate -> n (msresamp2.rs:137-152, :181 copy_from_slice)
+    int check_lengths(size_t nx, size_t ny, size_t *n) const {
+        const size_t big = interp ? ny : nx, small = interp ? nx : ny;
+        if (big != small * rate)
+            return fail(YAGI_ERR_CONFIG, "msresamp2: %s by %zu needs %zu %s samples for %zu %s samples (got %zu)",
+                        interp ? "interpolation" : "decimation", rate, small * rate, interp ? "output" : "input", small,
+                        interp ? "input" : "output", big);
+        *n = small;
+        return YAGI_OK;
+    }
 
     int init(bool interp_, size_t ns, const size_t *ms, const float *hf_all) {
         if (ns > 16) return fail(YAGI_ERR_CONFIG, "number of stages should not exceed 16");
@@ -2905,19 +2966,21 @@ struct MsResamp2Obj {
         *delay = 2 * (size_t)q->m - 1;                                                              \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
-    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) try { \
+    int yagi_hip_resamp2_##K##_execute_block(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y, size_t ny) try { \
         CHECK_Q(q);                                                                                 \
+        YG_TRY(q->check_lengths(mode, nx, ny));                                                     \
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->block_host(mode, x, nx, y);                                                       \
     } catch (...) { return ::yagi::api_exception(); }                                               \
-    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y) try { \
+    int yagi_hip_resamp2_##K##_execute_block_dev(yagi_hip_resamp2_##K q, int mode, const T *x, size_t nx, T *y, size_t ny) try { \
         CHECK_Q(q);                                                                                 \
+        YG_TRY(q->check_lengths(mode, nx, ny));                                                     \
         if (nx == 0) return YAGI_OK;                                                                \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
-        CHECK_NOALIAS(x, nx, y, q->out_count(mode, nx));                                            \
+        CHECK_NOALIAS(x, nx, y, ny);                                                                \
         return q->block_dev(mode, x, nx, y);                                                        \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_msresamp2_##K##_create_taps(int interp, size_t num_stages, const size_t *m_stage,  \
@@ -2986,19 +3049,23 @@ struct MsResamp2Obj {
         if (m_stage) for (size_t i = 0; i < q->num_stages; ++i) m_stage[i] = q->m_stage[i];         \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
-    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) try { \
+    int yagi_hip_msresamp2_##K##_execute_block(yagi_hip_msresamp2_##K q, const T *x, size_t nx, T *y, size_t ny) try { \
         CHECK_Q(q);                                                                                 \
+        size_t n = 0;                                                                               \
+        YG_TRY(q->check_lengths(nx, ny, &n));                                                       \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
         return q->block_host(x, n, y);                                                              \
     } catch (...) { return ::yagi::api_exception(); }                                               \
-    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x, size_t n, T *y) try { \
+    int yagi_hip_msresamp2_##K##_execute_block_dev(yagi_hip_msresamp2_##K q, const T *x, size_t nx, T *y, size_t ny) try { \
         CHECK_Q(q);                                                                                 \
+        size_t n = 0;                                                                               \
+        YG_TRY(q->check_lengths(nx, ny, &n));                                                       \
         if (n == 0) return YAGI_OK;                                                                 \
         CHECK_PTR(x);                                                                               \
         CHECK_PTR(y);                                                                               \
-        CHECK_NOALIAS(x, q->interp ? n : n * q->rate, y, q->interp ? n * q->rate : n);              \
+        CHECK_NOALIAS(x, nx, y, ny);                                                                \
         return q->block_dev(x, n, y);                                                               \
     } catch (...) { return ::yagi::api_exception(); }                                               \
     }

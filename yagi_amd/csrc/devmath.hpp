@@ -141,11 +141,7 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-}
-// the same with a cache-policy operand (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Data a kernel streams through exactly once
+// Cache-policy operand of the buffer / global accesses (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Data a kernel streams through exactly once
 // should neither evict the tables the resident workgroups re-read from L1 nor be kept in L2 / the Infinity Cache behind
 // the store: loads sc1 (L1 bypassed), stores nt.  Measured on the headline stream (freq_kernels.hip): -7 % together.
 // (-DYG_STREAM_LD= / -DYG_STREAM_ST= build the A/B variants of tools/ab_pkg.py.)
@@ -156,6 +152,42 @@ __device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff
 #define YG_STREAM_ST 2
 #endif
 constexpr int kStreamLoad = YG_STREAM_LD, kStreamStore = YG_STREAM_ST;
+__device__ __forceinline__ float2 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {    // streamed data
+    const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStreamLoad);
+    return make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+}
+// the same policies for accesses through plain pointers: a relaxed agent-scope atomic load IS `global_load ... sc1`,
+// a non-temporal store `global_store ... nt` (4-, 8- and, stores only, 16-byte types)
+template <class T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte samples");
+    if constexpr (kStreamLoad == 16) {
+        T v;
+        if constexpr (sizeof(T) == 4) {
+            const unsigned q = __hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_memcpy(&v, &q, 4);
+        } else {
+            const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_memcpy(&v, &q, 8);
+        }
+        return v;
+    } else {
+        return *p;
+    }
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T *p, T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "4-, 8- or 16-byte samples");
+    if constexpr (kStreamStore == 2) {
+        typedef float vec_t __attribute__((ext_vector_type(sizeof(T) / 4)));
+        vec_t q;
+        __builtin_memcpy(&q, &v, sizeof(T));
+        __builtin_nontemporal_store(q, reinterpret_cast<vec_t *>(p));
+    } else {
+        *p = v;
+    }
+}
 template <int AUX>
 __device__ __forceinline__ float2 buf_ld_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
@@ -171,13 +203,13 @@ __device__ __forceinline__ void buf_st_aux(__amdgpu_buffer_rsrc_t r, unsigned vo
 template <class T>
 __device__ __forceinline__ T buf_ld_t(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (sizeof(T) == 4) {
-        const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kStreamLoad);
         T v;
         __builtin_memcpy(&v, &q, 4);
         return v;
     } else {
         static_assert(sizeof(T) == 8, "4- or 8-byte samples");
-        const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        const v2u_t q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStreamLoad);
         T v;
         __builtin_memcpy(&v, &q, 8);
         return v;
@@ -187,7 +219,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     v2u_t q;
     q.x = __float_as_uint(v.x);
     q.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, kStreamStore);
 }
 
 

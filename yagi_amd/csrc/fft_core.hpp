@@ -153,7 +153,7 @@ __device__ __forceinline__ void fft4096_passes(float2 (&v)[16], float2 *__restri
         for (int bp = 0; bp < 16; ++bp) v[bp] = lds[bp * kEx2Stride + t];
         dft16<SIGN>(v);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) out[t + 256 * d] = v[dft16_pos(d)];
+        for (int d = 0; d < 16; ++d) st_stream(out + t + 256 * d, v[dft16_pos(d)]);
     }
     __syncthreads();                           // LDS free for the caller's next transform
 }

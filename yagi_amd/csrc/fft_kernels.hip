@@ -27,7 +27,7 @@ fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
         const float2 *src = in + b * 4096;
         float2 v[16];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = src[256 * a + threadIdx.x];
+        for (int a = 0; a < 16; ++a) v[a] = ld_stream(src + 256 * a + threadIdx.x);
         fft4096_passes<SIGN>(v, lds, tw, out + b * 4096);
     }
 }
@@ -56,14 +56,14 @@ fft_n256m_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const 
     const float2 *src = in + g * N;
     float2 v[16];
 #pragma unroll
-    for (int a = 0; a < 16; ++a) v[a] = live ? src[LT * a + u] : make_float2(0.f, 0.f);
+    for (int a = 0; a < 16; ++a) v[a] = live ? ld_stream(src + LT * a + u) : make_float2(0.f, 0.f);
     fft_n256m_passes_to_regs<SIGN, M>(v, lds, tw);
     if (live) {
         float2 *dst = out + g * N + u;
 #pragma unroll
         for (int i = 0; i < B; ++i)
 #pragma unroll
-            for (int d = 0; d < M; ++d) dst[LT * i + 256 * d] = v[i * M + d];
+            for (int d = 0; d < M; ++d) st_stream(dst + LT * i + 256 * d, v[i * M + d]);
     }
 }
 

@@ -275,7 +275,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     {
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (size_t)f * 4096, 32768u);
 #pragma unroll
-        for (unsigned a = 0; a < 16; ++a) v[a] = buf_ld_aux<kStreamLoad>(rx, 8u * t, 2048u * a);
+        for (unsigned a = 0; a < 16; ++a) v[a] = buf_ld(rx, 8u * t, 2048u * a);
     }
     __builtin_amdgcn_sched_barrier(0);
     lds[kOffT256 + (t >> 4) * kTRow + (t & 15u)] = tw_t;
@@ -303,7 +303,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(hs, 32768u);
         float2 hv[16];
 #pragma unroll
-        for (unsigned d = 0; d < 16; ++d) hv[d] = buf_ld(rh, 8u * t, 2048u * d);
+        for (unsigned d = 0; d < 16; ++d) hv[d] = buf_ld_aux<0>(rh, 8u * t, 2048u * d);      // a table: cached
 #pragma unroll
         for (unsigned d = 0; d < 16; ++d) v[d] = cmul(v[d], hv[d]);
     }
@@ -313,7 +313,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)f * 4096, 32768u);
 #pragma unroll
     for (unsigned d = 0; d < 16; ++d)
-        buf_st_aux<kStreamStore>(ro, 8u * t, 2048u * d, make_float2(v[d].x + u[d].x, v[d].y + u[d].y));
+        buf_st(ro, 8u * t, 2048u * d, make_float2(v[d].x + u[d].x, v[d].y + u[d].y));
 }
 
 __global__ void scale_cf32_kernel(const float2 *__restrict__ src, float s, float2 *__restrict__ dst, unsigned n) {

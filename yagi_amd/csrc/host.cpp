@@ -194,6 +194,49 @@ int window_value(int type, size_t i, size_t wlen, float arg, float *out) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-sample arithmetic of the FIR objects on the host mirror of their window (capi.hip DevWindow): what
+// FirFilter::execute (firfilt.rs:241-246), FirPfbFilter::execute (firpfb.rs:277-286) and
+// FirDecimationFilter::execute (firdecim.rs:179-191) compute, in the reference's order: products unfused, every
+// sum left to right from zero (dotprod/mod.rs:19-73: `iter().zip().map(|(a, b)| a * b).sum()`), the scale applied to
+// the finished sum.  This is product code (tens of nanoseconds per call), not the test oracle.
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+namespace {
+inline float h_mul(float a, float b) { return a * b; }
+inline cf32 h_mul(cf32 a, float b) { return cf32{a.re * b, a.im * b}; }
+inline cf32 h_mul(cf32 a, cf32 b) { return cf32{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline float h_add(float a, float b) { return a + b; }
+inline cf32 h_add(cf32 a, cf32 b) { return cf32{a.re + b.re, a.im + b.im}; }
+}  // namespace
+
+// FirFilter: the state is a VecDeque with the NEWEST sample first (push = rotate_right(1) + w[0] = x, :220-223), summed
+// against h[0..L) as two slices (dotprod/mod.rs:75-121): the ring wraps `split = L - head` samples from its start.
+// w = the window oldest first (w[L-1] = newest), head = the VecDeque's physical head.
+template <class T, class C>
+T host_fir_ring_dot(const T *w, size_t L, size_t head, const C *h, C scale) {
+    const size_t split = L - head;
+    T l{}, r{};
+    const T *newest = w + (L - 1);
+    for (size_t k = 0; k < split; ++k) l = h_add(l, h_mul(newest[-(ptrdiff_t)k], h[k]));
+    for (size_t k = split; k < L; ++k) r = h_add(r, h_mul(newest[-(ptrdiff_t)k], h[k]));
+    return h_mul(h_add(l, r), scale);
+}
+// Window-based objects: the contiguous window oldest first against the taps reversed (firdecim.rs:47, firpfb.rs:45-52);
+// h = the taps in natural order (h[0] meets the newest sample)
+template <class T, class C>
+T host_fir_window_dot(const T *w, size_t L, const C *h, C scale) {
+    T s{};
+    for (size_t k = 0; k < L; ++k) s = h_add(s, h_mul(w[k], h[L - 1 - k]));
+    return h_mul(s, scale);
+}
+template float host_fir_ring_dot<float, float>(const float *, size_t, size_t, const float *, float);
+template cf32 host_fir_ring_dot<cf32, float>(const cf32 *, size_t, size_t, const float *, float);
+template cf32 host_fir_ring_dot<cf32, cf32>(const cf32 *, size_t, size_t, const cf32 *, cf32);
+template float host_fir_window_dot<float, float>(const float *, size_t, const float *, float);
+template cf32 host_fir_window_dot<cf32, float>(const cf32 *, size_t, const float *, float);
+template cf32 host_fir_window_dot<cf32, cf32>(const cf32 *, size_t, const cf32 *, cf32);
+
 }  // namespace yagi
 
 extern "C" {
