@@ -99,7 +99,10 @@ for i, sp in enumerate(specs):
     name, _, lib = sp.partition("=")
     ya = import_build(f"{i}", lib)
     if i == 0:
-        ya.gen_complex_dev(0x59414749 + 2, NTOT, out=x, stream=S)
+        if os.environ.get("AB_ZERO"):      # all-zero input: same instructions and traffic, no switching activity
+            x.zero_()
+        else:
+            ya.gen_complex_dev(0x59414749 + 2, NTOT, out=x, stream=S)
         torch.cuda.synchronize()
     fn, units, bpu, keep = make(ya)
     arms.append({"name": name, "fn": fn, "units": units, "bpu": bpu, "keep": keep, "t": []})
@@ -113,7 +116,7 @@ for a in arms:
     if ref is None:
         ref = out
     else:
-        d = float(torch.linalg.vector_norm(out - ref) / torch.linalg.vector_norm(ref))
+        d = float(torch.linalg.vector_norm(out - ref) / (torch.linalg.vector_norm(ref) + 1e-30))
         print(f"{a['name']:12s} output vs {arms[0]['name']}: rel L2 {d:.2e}", flush=True)
 for _ in range(3):
     for a in arms:

@@ -617,6 +617,9 @@ class Resamp2(_FirBase):
 
     @classmethod
     def new(cls, kind, m, f0, as_):                           # Resamp2::new(m, f0, as_) :44
+        """The reference's signature with a Kaiser-windowed half-band prototype.  NOT tap-compatible with the reference,
+        whose prototype comes from its Parks-McClellan design code (resamp2.rs:58, out of scope): same structure, delay
+        and stop-band specification, different tap values.  For the reference's taps pass them to the constructor."""
         self = object.__new__(cls)
         self._init_kind(kind)
         self._prefix = f"yagi_hip_resamp2_{kind}_"

@@ -2613,22 +2613,30 @@ int yagi_hip_firpfbch2_crcf_analyzer_execute_sharded_dev(yagi_hip_firpfbch2_crcf
         comm->ev.push_back(e);
     }
     // the exchange stream must not run ahead of work already queued on the object's stream that still reads y
-    size_t done = 0, k = 0;
-    while (done < nsteps) {
-        const size_t ns = std::min(per, nsteps - done);
-        cf32 *sh = q->shard.as<cf32>() + done * Mr;
-        cf32 *ga = q->gathered.as<cf32>() + done * M;
-        YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(q, x + done * M2, ns, rank, R, sh));
-        YG_HIP(hipEventRecord(comm->ev[k], q->st));
-        YG_HIP(hipStreamWaitEvent(comm->st, comm->ev[k], 0));
-        YG_TRY(comm_all_gather(comm, sh, ga, ns * Mr * sizeof(cf32), comm->st));
-        YG_TRY(launch_firpfbch2_assemble(ga, ns, (int)M, R, y + done * M, comm->st));
-        done += ns;
-        ++k;
+    auto chunks = [&]() -> int {
+        size_t done = 0, k = 0;
+        while (done < nsteps) {
+            const size_t ns = std::min(per, nsteps - done);
+            cf32 *sh = q->shard.as<cf32>() + done * Mr;
+            cf32 *ga = q->gathered.as<cf32>() + done * M;
+            YG_TRY(yagi_hip_firpfbch2_crcf_analyzer_execute_shard_dev(q, x + done * M2, ns, rank, R, sh));
+            YG_HIP(hipEventRecord(comm->ev[k], q->st));
+            YG_HIP(hipStreamWaitEvent(comm->st, comm->ev[k], 0));
+            YG_TRY(comm_all_gather(comm, sh, ga, ns * Mr * sizeof(cf32), comm->st));
+            YG_TRY(launch_firpfbch2_assemble(ga, ns, (int)M, R, y + done * M, comm->st));
+            done += ns;
+            ++k;
+        }
+        return YAGI_OK;
+    };
+    const int rc = chunks();
+    // success or not: the object's stream waits for whatever the exchange stream was handed, so a later call cannot
+    // rewrite (or ensure() free) q->shard / q->gathered while a gather or an assemble still reads them
+    if (hipEventRecord(comm->done, comm->st) != hipSuccess || hipStreamWaitEvent(q->st, comm->done, 0) != hipSuccess) {
+        (void)hipStreamSynchronize(comm->st);
+        if (rc == YAGI_OK) return fail(YAGI_ERR_DEVICE, "joining the exchange stream failed");
     }
-    YG_HIP(hipEventRecord(comm->done, comm->st));
-    YG_HIP(hipStreamWaitEvent(q->st, comm->done, 0));
-    return YAGI_OK;
+    return rc;
 } catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firpfbch2_crcf_assemble_dev(const yagi_cf32 *gathered, size_t nsteps, size_t M, int nranks,
                                          yagi_cf32 *y, yagi_stream_t s) try {

@@ -95,7 +95,9 @@ int yagi_hip_comm_create(const unsigned char *id, int rank, int nranks, yagi_hip
     *out = nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(YAGI_ERR_CONFIG, "bad rank %d of %d", rank, nranks);
     YG_TRY(rccl_ready());
-    std::unique_ptr<yagi_hip_comm_s> c(new (std::nothrow) yagi_hip_comm_s);
+    // released through yagi_hip_comm_destroy on every failure path below: communicator, stream and events alike
+    struct Destroy { void operator()(yagi_hip_comm_s *p) const { (void)yagi_hip_comm_destroy(p); } };
+    std::unique_ptr<yagi_hip_comm_s, Destroy> c(new (std::nothrow) yagi_hip_comm_s);
     if (!c) return fail(YAGI_ERR_INTERNAL, "out of memory");
     ncclUniqueId u;
     std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
