@@ -123,6 +123,24 @@ for _ in range(3):
         a["fn"]()
 torch.cuda.synchronize()
 inner = 4
+if os.environ.get("AB_SMI"):               # board power and shader clock while each arm loops (~3 s per arm)
+    import subprocess, threading, time
+    def smi():
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        pw = [l.split(":")[-1].strip() for l in out.splitlines() if "Power (W)" in l]
+        ck = [l.split("(")[-1].rstrip(")") for l in out.splitlines() if "sclk" in l]
+        return f"{pw[0] if pw else '?'} W, sclk {ck[0] if ck else '?'}"
+    for a in arms:
+        res = []
+        th = threading.Thread(target=lambda: (time.sleep(1.2), res.append(smi()), res.append(smi())))
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            for _ in range(8):
+                a["fn"]()
+            torch.cuda.synchronize()
+        th.join()
+        print(f"{a['name']:12s} under load: {' | '.join(res)}", flush=True)
 for r in range(ROUNDS):
     for a in (arms if r % 2 == 0 else arms[::-1]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -239,15 +239,22 @@ int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
     if (n == 0) return YAGI_OK;
     w.npush += n;
     const bool conv = kernel_choice == 4 && L <= 2049;
+    // auto: the matrix-pipe Toeplitz form where it exists (<= 256 taps) and the block fills the chip -- the same sums as
+    // the sliding vector form (both exact on integer data), but the vector form runs into the chip's power cap on
+    // random data (0.63 of the FP32 peak, 0.80 on all-zero input) and the matrix form does not (0.72 either way:
+    // profiles/r03_notes.md); else the register-sliding vector form
+    const bool mfma = Lm && (kernel_choice == 3 || (kernel_choice == 0 && n >= ((size_t)1 << 16)));
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
     if (conv) {
         YG_TRY(prepare_conv());
         YG_TRY(launch_fir_crcf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
         w.flip();
         return YAGI_OK;
-    } else if (kernel_choice == 3 && Lm)
-        YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st));
-    else if (slide && Lp <= kSlideMaxTaps) {
+    } else if (mfma) {
+        YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st, w.next()));
+        w.flip();
+        return YAGI_OK;
+    } else if (slide && Lp <= kSlideMaxTaps) {
         YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st, w.next()));
         w.flip();                                   // the kernel's last workgroup wrote the next window
         return YAGI_OK;

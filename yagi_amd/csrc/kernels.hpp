@@ -84,7 +84,7 @@ int mfma_lp_for(int L);
 size_t toeplitz_pack_floats(int Lp);
 void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack_host);
 int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lm, float scale,
-                         cf32 *y, size_t ny, hipStream_t st);
+                         cf32 *y, size_t ny, hipStream_t st, cf32 *win_next = nullptr);
 
 // Fast convolution (overlap-save, 4096-pt blocks) form of firfilt_crcf: hs = FFT_4096{[h;0]} (unscaled),
 // forward table twf, backward table twb; 1 <= L <= 2049.

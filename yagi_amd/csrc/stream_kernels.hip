@@ -14,6 +14,7 @@
 //     roofline that bounds a direct-form 256-tap crcf filter on MI355X (64 flop/B).
 // Algorithmic HBM traffic: 8 B read + 8 B written per sample (16 B/sample) in both kernels; in
 // the fused kernel the FIR output goes registers -> LDS -> FFT registers and never touches HBM.
+#include <algorithm>
 #include <type_traits>
 
 #include "fft_core.hpp"
@@ -313,10 +314,17 @@ template <int NS, bool FUSED, int NW, int TILE>
 __global__ void __launch_bounds__(64 * NW, (TILE == 2048 && NW == 4) ? 4 : 1)
 fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                      const float *__restrict__ apack, int L, int Lp, float scale,
-                     const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units, bool direct) {
+                     const float2 *__restrict__ tw, float2 *__restrict__ out, size_t n_units, bool direct,
+                     float2 *__restrict__ win_next) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
     const int wave = threadIdx.x >> 6;
+    // the filter window after the block: the last L samples of (window ++ x), by the last workgroup (plain filter only)
+    if (!FUSED && win_next != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int j = threadIdx.x; j < L; j += 64 * NW) {
+            const size_t c = n_units + (size_t)j;
+            win_next[j] = (c < (size_t)L) ? win[c] : x[c - (size_t)L];
+        }
     static_assert(!FUSED || TILE == kTile, "the fused form transforms whole frames");
     constexpr int NT = TILE / 512 / NW;          // tasks per wave
     static_assert(NT >= 1 && NT * NW * 512 == TILE, "tile = NW x NT tasks of 512 outputs");
@@ -408,7 +416,7 @@ void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack) {
 #endif
 template <int NS, bool FUSED, int NW>
 static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
-                         const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
+                         const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st, cf32 *win_next) {
     constexpr int TILE = FUSED ? kTile : YG_MFMA_TILE;
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW, TILE>), raised));
@@ -419,7 +427,139 @@ static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int
     fir_crcf_mfma_kernel<NS, FUSED, NW, TILE><<<grid, 64 * NW, lds, st>>>(
         reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, Lp, scale,
         reinterpret_cast<const float2 *>(tw), reinterpret_cast<float2 *>(out), n_units,
-        !FUSED && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0);
+        !FUSED && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0, reinterpret_cast<float2 *>(win_next));
+    YG_LAUNCH_CHECK();
+    return YAGI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The plain filter as a PERSISTENT matrix-pipe kernel: a workgroup walks the tiles b, b + G, b + 2G, ... of 2048
+// outputs and keeps the pipe fed across tiles -- the 16-byte-per-step tap registers are loaded once per workgroup, the
+// next tile's span goes from HBM straight into the OTHER span buffer while the current tile's MFMA phase runs (LDS-DMA
+// buffer loads: no registers held, no LDS write instructions), and one barrier per tile hands the buffers over.  In the one-tile-per-workgroup form every wave stages, waits, computes and stores in turn and the pipe
+// idles whenever the four waves of a SIMD are all outside their MFMA phase (84 % busy, profiles/r02_pmc_mfma.txt).
+// Span layout: 2 float2 of padding per 64 samples, so the B operand of lane (seg, k, c) sits on bank
+// (132 seg + 2 k + c) mod 32 -- the eight segments of a wave instruction on eight different banks (the shared
+// 17/16 row layout of the sliding kernel put segments s and s + 4 on one bank: 47 % of this kernel's LDS cycles).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMTile = 2048;
+__host__ __device__ __forceinline__ constexpr int pad2(int i) { return i + 2 * (i >> 6); }
+
+template <int NS>
+__device__ __forceinline__ void fir_task_mfma2(f32x4 (&acc)[4], const float (&a)[NS],
+                                               const float *__restrict__ xsf, int T0) {
+    const int lane = threadIdx.x & 63;
+    const int k = lane >> 4, j = lane & 15, seg = j >> 1, c = j & 1;
+    // span index i = T0 + 64 seg + 4 sp + k ; pad2(i) = i + 2 (T0 >> 6) + 2 seg + 2 (sp >> 4)
+    const float *p = xsf + 2 * (T0 + 2 * (T0 >> 6) + 66 * seg + k) + c;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PF = 6;
+    float bq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) bq[i] = p[2 * (4 * i + 2 * (i >> 4))];
+#pragma unroll
+    for (int sp = 0; sp < NS + 12; ++sp) {
+        const float b = bq[sp % PF];
+        if (sp + PF < NS + 12) {
+            bq[sp % PF] = p[2 * (4 * (sp + PF) + 2 * ((sp + PF) >> 4))];
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int s = sp - 4 * tt;
+            if (s >= 0 && s < NS) {
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b, acc[tt], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // then this MFMA
+            }
+        }
+    }
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256, 4)
+fir_crcf_mfma_stream_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
+                            const float *__restrict__ apack, int L, float scale, float2 *__restrict__ out, size_t n,
+                            float2 *__restrict__ win_next, unsigned ntiles) {
+    constexpr int Lp = 4 * NS - 16;                    // 68 -> 256 taps, 36 -> 128, 20 -> 64
+    constexpr int SPAN = kMTile + Lp;                  // samples a tile reads: outputs + Lp - 1 of history (+ 1)
+    constexpr int NLD = (SPAN + 255) / 256;
+    constexpr int NCH = ((SPAN + 31) / 32 + 3) / 4;    // 256-byte chunks per wave
+    constexpr bool NCH4 = ((SPAN + 31) / 32) % 4 == 0;
+    constexpr int BUF = pad2(SPAN + 64);
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *xs = reinterpret_cast<float2 *>(smem);
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);       // scalar: M0 and the chunk offsets hang on it
+    if (win_next != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int j = t; j < L; j += 256) {
+            const size_t c = n + (size_t)j;
+            win_next[j] = (c < (size_t)L) ? win[c] : x[c - (size_t)L];
+        }
+    unsigned tile = blockIdx.x;
+    {   // first tile of the workgroup: the only one that can reach back into the window
+        const long long base = (long long)tile * kMTile - (Lp - 1);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int u = t + 256 * q;
+            const long long idx = base + u;
+            float2 v = make_float2(0.f, 0.f);
+            if (idx >= 0) { if (idx < (long long)n) v = ld_stream(x + idx); }
+            else if (idx >= -(long long)L) v = win[L + idx];
+            if (u < SPAN) xs[pad2(u)] = v;
+        }
+    }
+    float a[NS];
+    load_apack<NS>(a, apack);
+    __syncthreads();
+    int cur = 0;
+    const int lane = t & 63;
+    for (;;) {
+        const unsigned next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) {
+            // the next tile's span straight from HBM into the other buffer (LDS-DMA: no registers held across the MFMA
+            // phase): a wave instruction moves 256 contiguous bytes = half a 64-sample row; beyond n the descriptor reads
+            // zero.  next >= 1, so the span starts inside x.
+            const size_t s0 = (size_t)next * kMTile - (Lp - 1);
+            const size_t avail = n - s0;
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + s0, (unsigned)(avail < (size_t)SPAN ? avail : (size_t)SPAN) * 8u);
+            float2 *dst = xs + (cur ^ 1) * BUF;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = wave + 4 * i;            // chunk of 32 samples
+                if (NCH4 || c < (SPAN + 31) / 32)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(dst + pad2(32 * c)), 4,
+                                                             4 * lane, 256 * c, 0, kStreamLoad);
+            }
+        }
+        f32x4 acc[4];
+        fir_task_mfma2<NS>(acc, a, reinterpret_cast<const float *>(xs + cur * BUF), 512 * wave);
+        __syncthreads();                               // the DMA has landed (vmcnt) and every wave is done with `cur`
+        store_task_direct(acc, out, (size_t)tile * kMTile, (long long)(n - (size_t)tile * kMTile), 512 * wave, scale);
+        if (!has_next) break;
+        cur ^= 1;
+        tile = next;
+    }
+}
+
+template <int NS>
+static int launch_mfma_stream(const cf32 *win, const cf32 *x, const float *apack, int L, float scale, cf32 *out, size_t n,
+                              hipStream_t st, cf32 *win_next) {
+    constexpr int Lp = 4 * NS - 16, SPAN = kMTile + Lp, BUF = pad2(SPAN + 64);
+    const size_t ntiles = (n + kMTile - 1) / kMTile;
+    if (ntiles > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        YG_HIP(hipGetDevice(&dev));
+        YG_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+        const unsigned grid = (unsigned)std::min<size_t>(ntiles, (size_t)cus * 4);       // four workgroups per CU stay resident (3: +0.9 %, 2: +2.8 %, 5: +13.5 %)
+    fir_crcf_mfma_stream_kernel<NS><<<grid, 256, 2 * BUF * sizeof(float2), st>>>(
+        reinterpret_cast<const float2 *>(win), reinterpret_cast<const float2 *>(x), apack, L, scale,
+        reinterpret_cast<float2 *>(out), n, reinterpret_cast<float2 *>(win_next), (unsigned)ntiles);
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
@@ -429,19 +569,27 @@ static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int
 #endif
 template <bool FUSED>
 static int launch_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
-                       const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st) {
+                       const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st, cf32 *win_next = nullptr) {
     switch (Lp) {
-        case 64: return launch_mfma_t<20, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
-        case 128: return launch_mfma_t<36, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
-        case 256: return launch_mfma_t<68, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st);
+        case 64: return launch_mfma_t<20, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
+        case 128: return launch_mfma_t<36, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
+        case 256: return launch_mfma_t<68, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
     }
     return fail(YAGI_ERR_INTERNAL, "mfma FIR: unsupported padded length %d", Lp);
 }
 
 int launch_fir_crcf_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
-                         cf32 *y, size_t ny, hipStream_t st) {
+                         cf32 *y, size_t ny, hipStream_t st, cf32 *win_next) {
     if (ny == 0) return YAGI_OK;
-    return launch_mfma<false>(win, x, apack, L, Lp, scale, nullptr, y, ny, st);
+    // blocks of at least one tile per resident workgroup, 16-byte aligned output: the persistent form
+    if (ny >= ((size_t)1 << 21) && (reinterpret_cast<unsigned long long>(y) & 15ull) == 0 && ny < ((size_t)1 << 31)) {
+        switch (Lp) {
+            case 64: return launch_mfma_stream<20>(win, x, apack, L, scale, y, ny, st, win_next);
+            case 128: return launch_mfma_stream<36>(win, x, apack, L, scale, y, ny, st, win_next);
+            case 256: return launch_mfma_stream<68>(win, x, apack, L, scale, y, ny, st, win_next);
+        }
+    }
+    return launch_mfma<false>(win, x, apack, L, Lp, scale, nullptr, y, ny, st, win_next);
 }
 
 // ---------------------------------------------------------------------------------------------
