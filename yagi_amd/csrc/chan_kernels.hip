@@ -27,13 +27,12 @@
 #include "fft_radix.hpp"
 #include "kernels.hpp"
 
-#ifndef YG_ANA_LD
-#define YG_ANA_LD 0
-#endif
-#ifndef YG_ANA_ST
-#define YG_ANA_ST 0
-#endif
 namespace yagi {
+
+// Cache policy of the analyzers' streamed accesses (interleaved A/B, profiles/r03_notes.md): sample loads sc1 (L1
+// bypassed) -1.4 ... -1.6 %; channel stores stay plain -- their 64- to 128-byte runs per wave instruction lose 2.8 ... 3.6 %
+// as non-temporal stores (the synthesizers, whose stores are whole lines, gain 2 % and use the library default).
+constexpr int kAnaLoad = kStreamLoad, kAnaStore = 0;
 
 struct FacList { int n; int f[16]; };
 
@@ -243,7 +242,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     auto load8 = [&](float2 (&d)[kColHalf], int t) {
 #pragma unroll
         for (int j = 0; j < kColHalf; ++j) {
-            if constexpr (FULL) d[j] = buf_ld_aux<YG_ANA_LD>(rx, vx, 8u * ((unsigned)(t + j) << lgM));
+            if constexpr (FULL) d[j] = buf_ld_aux<kAnaLoad>(rx, vx, 8u * ((unsigned)(t + j) << lgM));
             else d[j] = (t + j < nvalid) ? xg[(unsigned)(t + j) << lgM] : make_float2(0.f, 0.f);
         }
     };
@@ -278,7 +277,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
             stockham_last_pass_out<R1, -1>(vb, M, nq, twl, 1, true, pitch, [&](int q, int k, float2 v) {
                 const int gq = q / kColHalf, fr = q - gq * kColHalf;
                 if constexpr (FULL)
-                    buf_st_aux<YG_ANA_ST>(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), v);
+                    buf_st_aux<kAnaStore>(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), v);
                 else if (t + fr < group_frames(gq))
                     yb[((unsigned)(gq * run + t + fr) << lgM) + k] = v;
             });
@@ -295,7 +294,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
             const int q = e >> lgM, k = e & (M - 1);
             const int gq = q / kColHalf, fr = q - gq * kColHalf;
             if constexpr (FULL)
-                buf_st_aux<YG_ANA_ST>(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), res[q * pitch + k]);
+                buf_st_aux<kAnaStore>(ry, 8u * (((unsigned)(gq * run + fr) << lgM) + k), 8u * ((unsigned)t << lgM), res[q * pitch + k]);
             else if (t + fr < group_frames(gq))
                 yb[((unsigned)(gq * run + t + fr) << lgM) + k] = res[q * pitch + k];
         }
@@ -393,7 +392,7 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
         for (int j = 0; j < HF; ++j)
 #pragma unroll
             for (int cc = 0; cc < C; ++cc)
-                if constexpr (FULL) d[cc][j] = buf_ld_aux<YG_ANA_LD>(rx, 8u * (t + 256u * cc), 8u * ((unsigned)(f + j) << lgM));
+                if constexpr (FULL) d[cc][j] = buf_ld_aux<kAnaLoad>(rx, 8u * (t + 256u * cc), 8u * ((unsigned)(f + j) << lgM));
                 else d[cc][j] = (f + j < nvalid) ? xg[((unsigned)(f + j) << lgM) + 256u * cc] : make_float2(0.f, 0.f);
     };
     float2 *yb = y + f_begin * M;
@@ -425,7 +424,7 @@ firpfbch_wide_kernel(const float2 *__restrict__ hist, const float2 *__restrict__
         for (int i = 0; i < HF * C; ++i) {
             const int e = t + 256 * i;
             const int q = e >> lgM, k = e & (M - 1);
-            if constexpr (FULL) buf_st_aux<YG_ANA_ST>(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)f << lgM), vb[q * pitch + k]);
+            if constexpr (FULL) buf_st_aux<kAnaStore>(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)f << lgM), vb[q * pitch + k]);
             else if (f + q < nvalid) yb[((unsigned)(f + q) << lgM) + k] = vb[q * pitch + k];
         }
         __syncthreads();
@@ -930,7 +929,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     auto load4 = [&](float2 (&d)[kPairs], int t /* first step of the half tile */) {
 #pragma unroll
         for (int kk = 0; kk < kPairs; ++kk) {
-            if constexpr (FULL) d[kk] = buf_ld_aux<YG_ANA_LD>(rx, vx, 8u * ((unsigned)(t / 2 + kk) << lgM));
+            if constexpr (FULL) d[kk] = buf_ld_aux<kAnaLoad>(rx, vx, 8u * ((unsigned)(t / 2 + kk) << lgM));
             else d[kk] = (t + 2 * kk + bpar < nvalid) ? xg[(unsigned)(t / 2 + kk) << lgM] : make_float2(0.f, 0.f);
         }
     };
@@ -991,7 +990,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                 stockham_last_pass_out<R1, +1>(vb, M, nq, twl, 1, true, pitch, [&](int q, int k, float2 v) {
                     const int gq = q / kColHalf, sl = q - gq * kColHalf;
                     if constexpr (FULL)
-                        buf_st_aux<YG_ANA_ST>(ry, 8u * (((unsigned)(gq * run + sl) << lgM) + k), 8u * ((unsigned)t << lgM),
+                        buf_st_aux<kAnaStore>(ry, 8u * (((unsigned)(gq * run + sl) << lgM) + k), 8u * ((unsigned)t << lgM),
                                make_float2(v.x * invM, v.y * invM));
                     else if (t + sl < group_steps(gq))
                         yb[(size_t)(gq * run + t + sl) * M + k] = make_float2(v.x * invM, v.y * invM);
@@ -1013,7 +1012,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             const int gq = q / kColHalf, sl = q - gq * kColHalf;
             if constexpr (FULL) {
                 const float2 v = res[q * pitch + k];
-                buf_st_aux<YG_ANA_ST>(ry, 8u * ((unsigned)(gq * run + sl) * Mr + k), 8u * ((unsigned)t * Mr),
+                buf_st_aux<kAnaStore>(ry, 8u * ((unsigned)(gq * run + sl) * Mr + k), 8u * ((unsigned)t * Mr),
                        make_float2(v.x * invM, v.y * invM));
             } else if (t + sl < group_steps(gq)) {
                 const float2 v = res[q * pitch + k];
@@ -1121,7 +1120,7 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
 #pragma unroll
             for (int kk = 0; kk < HP; ++kk) {
                 if constexpr (FULL)
-                    d[cc][kk] = buf_ld_aux<YG_ANA_LD>(rx, 8u * (unsigned)(bpar * M2 + pos[cc]), 8u * ((unsigned)(st / 2 + kk) << lgM));
+                    d[cc][kk] = buf_ld_aux<kAnaLoad>(rx, 8u * (unsigned)(bpar * M2 + pos[cc]), 8u * ((unsigned)(st / 2 + kk) << lgM));
                 else
                     d[cc][kk] = (st + 2 * kk + bpar < nvalid) ? xg[(unsigned)(st / 2 + kk) << lgM] : make_float2(0.f, 0.f);
             }
@@ -1169,7 +1168,7 @@ firpfbch2_wide_kernel(const float2 *__restrict__ hist, int hist_len, const float
             const int q = e >> lgM, k = e & (M - 1);
             if constexpr (FULL) {
                 const float2 v = vb[q * pitch + k];
-                buf_st_aux<YG_ANA_ST>(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)st << lgM), make_float2(v.x * invM, v.y * invM));
+                buf_st_aux<kAnaStore>(ry, 8u * (((unsigned)q << lgM) + k), 8u * ((unsigned)st << lgM), make_float2(v.x * invM, v.y * invM));
             } else if (st + q < nvalid) {
                 const float2 v = vb[q * pitch + k];
                 yb[((unsigned)(st + q) << lgM) + k] = make_float2(v.x * invM, v.y * invM);
