@@ -432,18 +432,23 @@ def main():
             cfg[name] = e
 
         for kname, kern, note in (("C2_firfilt_crcf_256_default", 0, "FirFilter::execute_block default kernel "
-                                   "(direct form, bit-exact on integers), 2^28-sample stream in 2^24 blocks"),
+                                   "(direct form on the matrix pipe: fir_crcf_mfma_stream_kernel<68>, bit-exact on "
+                                   "integers), 2^28-sample stream in 2^24 blocks"),
                                   ("C2_firfilt_crcf_256_kernel4", 4, "set_kernel(4): overlap-save fast convolution, "
                                    "same stream")):
             qf = ya.FirFilter("crcf", h)
             qf.set_scale(scale)
             qf.set_kernel(kern)
             qf.set_stream(stream.cuda_stream)
+            qf.set_pipeline(not args.no_pipeline)
 
             def run(qf=qf):
                 for xb, yb in blocks:
                     qf.execute_block_dev(xb, n, yb)
-            leg(kname, run, ntot, 16, note, flop_per_unit=4 * TAPS if kern == 0 else None)
+                qf.join()
+            leg(kname, run, ntot, 16, note + ("; pipelined block calls, joined once per pass" if not args.no_pipeline
+                                             else "; plain block calls"),
+                flop_per_unit=4 * TAPS if kern == 0 else None)
         # C1 (BASELINE configs[0], the reference's own CPU-runnable case): firfilt_rrrf 63 taps over 1 M real samples.
         # GPU: ONE execute_block_dev call on device-resident data (launch-bound at this size), and the host-pointer
         # call (H2D + kernel + D2H); CPU: the oracle's FirFilter::execute_block on the same samples, one thread.

@@ -155,6 +155,8 @@ int yagi_hip_dotprod_cccf_dev(const yagi_cf32 *a, const yagi_cf32 *b, size_t n, 
                                              size_t ny);                                            \
     int yagi_hip_firfilt_##K##_execute_block_dev(yagi_hip_firfilt_##K q, const T *x_dev, size_t n,  \
                                                  T *y_dev);                                         \
+    int yagi_hip_firfilt_##K##_set_pipeline(yagi_hip_firfilt_##K q, int on);  /* as yagi_hip_firfft_crcf_set_pipeline: */ \
+    int yagi_hip_firfilt_##K##_join(yagi_hip_firfilt_##K q);  /* consecutive execute_block_dev calls overlap; y_dev and x_dev's reuse are ordered after join */ \
     int yagi_hip_firfilt_##K##_set_scale(yagi_hip_firfilt_##K q, C scale);                          \
     int yagi_hip_firfilt_##K##_get_scale(yagi_hip_firfilt_##K q, C *scale);                         \
     int yagi_hip_firfilt_##K##_get_length(yagi_hip_firfilt_##K q, size_t *h_len);                   \

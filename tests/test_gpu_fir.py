@@ -699,3 +699,40 @@ def test_per_sample_firpfb_and_firdecim_on_the_host_mirror(ya, oracle, kind):
     assert np.array([a]).astype(x.dtype).tobytes() == np.array([b]).astype(x.dtype).tobytes()
     with pytest.raises(ya.ConfigError):
         qd.execute(x[:M - 1])                            # firdecim.rs:182 indexes x[i] for i < M
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_firfilt_pipelined_blocks_bit_identical(ya, kind):
+    """set_pipeline(1) on FirFilter: consecutive execute_block_dev calls run on two streams of the object, each reading its
+    window from the tail of the previous call's input; after join() every output is bit for bit the unpipelined one --
+    every kernel choice, ragged blocks (shorter than the filter: those calls join and run unpipelined), per-sample and
+    host-pointer calls and a reset in between"""
+    rng = np.random.default_rng(77)
+    T = ya.KINDS[kind][0]
+    for L, choices in ((31, (0, 1, 4)), (256, (0, 1, 2, 3, 4) if kind == "crcf" else (0, 1, 4))):
+        h = rand_taps(rng, kind, L)
+        sizes = [1 << 16, 5000, 17, 1 << 17, 300, 1 << 16, 1 << 21, 4096]
+        x = rand_samples(rng, kind, sum(sizes))
+        dx = ya.DeviceArray.from_numpy(x)
+        for choice in choices:
+            plain, piped = ya.FirFilter(kind, h), ya.FirFilter(kind, h)
+            for q in (plain, piped):
+                q.set_scale(0.4)
+                q.set_kernel(choice)
+            piped.set_pipeline(True)
+            dy0, dy1 = ya.DeviceArray(x.size, T), ya.DeviceArray(x.size, T)
+            isz = x.dtype.itemsize
+            for rep in range(2):
+                for q, dy in ((plain, dy0), (piped, dy1)):
+                    o = 0
+                    for n in sizes:
+                        q.execute_block_dev(dx.ptr + isz * o, n, dy.ptr + isz * o)
+                        o += n
+                piped.join()
+                a, b = dy0.to_numpy(), dy1.to_numpy()
+                assert a.tobytes() == b.tobytes(), (kind, L, choice, rep)
+                if rep == 0:
+                    # per-sample call (host mirror: joins and fetches the window), host-pointer block, then reset
+                    assert plain.execute_one(1.0) == piped.execute_one(1.0)
+                    assert plain.execute_block(x[:1000]).tobytes() == piped.execute_block(x[:1000]).tobytes()
+                    plain.reset(); piped.reset()

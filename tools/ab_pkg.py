@@ -68,9 +68,13 @@ def make(ya):
     if workload in ("c2", "c2k3", "c2k4"):
         q = ya.FirFilter("crcf", h); q.set_scale(0.4); q.set_stream(S)
         q.set_kernel({"c2": 0, "c2k3": 3, "c2k4": 4}[workload])
+        if os.environ.get("AB_PIPE") and hasattr(q, "set_pipeline"):
+            q.set_pipeline(True)
         def run():
             for b in range(16):
                 q.execute_block_dev(xp + 8 * n * b, n, yp + 8 * n * b)
+            if hasattr(q, "join"):
+                q.join()
         return run, NTOT, 16, q
     nc = 1 << 26
     if workload == "c4":

@@ -315,6 +315,14 @@ class FirFilter(_FirBase):
     def execute_block_dev(self, x_dev, n, y_dev):
         _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
 
+    def set_pipeline(self, on=True):
+        """pipelined block calls (include/yagi_hip.h): consecutive execute_block_dev calls overlap on two streams of the
+        object; outputs (and the right to overwrite the inputs) are ordered on the object's stream after join()"""
+        _check(self._fn("set_pipeline")(self._h, 1 if on else 0))
+
+    def join(self):
+        _check(self._fn("join")(self._h))
+
     def get_length(self):                                    # :301-303
         n = C.c_size_t()
         _check(self._fn("get_length")(self._h, C.byref(n)))

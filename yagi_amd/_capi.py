@@ -90,6 +90,8 @@ for _k, (_T, _Cc) in KIND_TYPES.items():
     _sig(p + "execute_one", vp, _T, vp)
     _sig(p + "execute_block", vp, vp, sz, vp, sz)
     _sig(p + "execute_block_dev", vp, vp, sz, vp)
+    _sig(p + "set_pipeline", vp, ci)
+    _sig(p + "join", vp)
     _sig(p + "set_scale", vp, _Cc)
     _sig(p + "get_scale", vp, vp)
     _sig(p + "get_length", vp, C.POINTER(sz))

@@ -54,6 +54,37 @@ static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
     return YAGI_OK;
 }
 
+// Pipelined block calls (yagi_hip_firfft_crcf_set_pipeline, yagi_hip_firfilt_*_set_pipeline).  Consecutive blocks of the stream depend on each other
+// only through the L-sample filter window, and that window is INPUT data (the previous block's last L samples), which
+// the pipelined contract keeps intact until the join: block b + 1 reads it straight from the previous call's x, so it
+// needs nothing block b computes.  The block kernels alternate between two streams owned by the handle; call b does
+//     caller's stream: record `in`           lane b & 1: wait(in), block kernel b, record done[b & 1]
+// so block b + 1 ramps up while block b drains (on one stream every kernel waits for the complete drain of the one
+// before it: ~4 us of a 61 us block).  The caller's stream is NOT made to wait per call (its next `in` would inherit
+// that wait and serialise the blocks); it joins the lanes in *_join (DevWindow::join), which every other use of the
+// object's window goes through first and which also copies the last block's tail into the object's window.
+struct StreamPipe {
+    bool on = false;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t in = nullptr, done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    unsigned calls = 0;
+    const void *prev_tail = nullptr;      // last L samples of the previous pipelined block (null: use the object's window)
+    int init() {
+        if (lane[0]) return YAGI_OK;
+        for (auto &s : lane) YG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        YG_HIP(hipEventCreateWithFlags(&in, hipEventDisableTiming));
+        for (auto &e : done) YG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return YAGI_OK;
+    }
+    ~StreamPipe() {
+        for (auto &s : lane)
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (in) (void)hipEventDestroy(in);
+        for (auto &e : done) if (e) (void)hipEventDestroy(e);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Device window of the last `len` samples + host push queue
 // ---------------------------------------------------------------------------------------------
@@ -74,6 +105,42 @@ struct DevWindow {
     size_t hend = 0;
     bool host_valid = true, dev_valid = true;
     uint64_t npush = 0;               // samples pushed since the window was made: the ring position of FirFilter's VecDeque
+    StreamPipe pipe;                  // pipelined block calls (objects that offer set_pipeline)
+
+    // the caller's stream waits for every block handed to the lanes, then takes over the filter window (the last block's
+    // tail); every other access to the window comes through here first
+    int join(hipStream_t st) {
+        for (int i = 0; i < 2; ++i) {
+            if (pipe.busy[i]) YG_HIP(hipStreamWaitEvent(st, pipe.done[i], 0));
+            pipe.busy[i] = false;
+        }
+        if (pipe.prev_tail) {
+            YG_TRY(launch_update_window<T>(dev(), static_cast<const T *>(pipe.prev_tail), (size_t)len, len, next(), st));
+            flip();
+            pipe.prev_tail = nullptr;
+        }
+        return YAGI_OK;
+    }
+    // one pipelined block: the caller's stream records `in`, lane (calls & 1) waits for it; returns the lane and the
+    // window the block kernel reads.  finish_piped() after the launch.
+    int begin_piped(hipStream_t st, hipStream_t *lane, const T **win) {
+        const int i = (int)(pipe.calls & 1u);
+        YG_HIP(hipEventRecord(pipe.in, st));
+        YG_HIP(hipStreamWaitEvent(pipe.lane[i], pipe.in, 0));
+        *lane = pipe.lane[i];
+        *win = pipe.prev_tail ? static_cast<const T *>(pipe.prev_tail) : dev();
+        return YAGI_OK;
+    }
+    int finish_piped(const T *x, size_t n) {          // n >= len
+        const int i = (int)(pipe.calls & 1u);
+        YG_HIP(hipEventRecord(pipe.done[i], pipe.lane[i]));
+        pipe.busy[i] = true;
+        ++pipe.calls;
+        pipe.prev_tail = x + (n - (size_t)len);
+        host_valid = false;
+        return YAGI_OK;
+    }
+    bool can_pipe(size_t n) const { return pipe.on && dev_valid && n >= (size_t)len; }
 
     int init(int n, hipStream_t st) {
         len = n;
@@ -83,6 +150,7 @@ struct DevWindow {
         return reset(st);
     }
     int reset(hipStream_t st) {       // zeroes the samples in place; the ring position is kept (firfilt.rs:209-213)
+        YG_TRY(join(st));
         YG_HIP(hipMemsetAsync(buf[cur].p, 0, (size_t)len * sizeof(T), st));
         std::fill(hbuf.begin(), hbuf.begin() + len, T{});
         hend = (size_t)len;
@@ -112,6 +180,7 @@ struct DevWindow {
     }
     // the device window is what the block kernels read: bring it up to date with the host mirror
     int ensure_dev(hipStream_t st) {
+        YG_TRY(join(st));
         if (dev_valid) return YAGI_OK;
         YG_HIP(hipMemcpyAsync(buf[cur].p, host(), (size_t)len * sizeof(T), hipMemcpyHostToDevice, st));
         YG_HIP(hipStreamSynchronize(st));
@@ -120,6 +189,7 @@ struct DevWindow {
     }
     // the host mirror is what the per-sample calls read: fetch the window a block kernel left on the device
     int ensure_host(hipStream_t st) {
+        YG_TRY(join(st));
         if (host_valid) return YAGI_OK;
         YG_HIP(hipMemcpyAsync(hbuf.data(), buf[cur].p, (size_t)len * sizeof(T), hipMemcpyDeviceToHost, st));
         YG_HIP(hipStreamSynchronize(st));
@@ -214,56 +284,62 @@ struct FirFilt {
 // execute_block on device data.  The auto choice is always a direct form (the dotprod sums of the reference,
 // exact on integer-valued data); the overlap-save kernel (kernel_choice 4) is opt-in for every type
 // combination: 2.5x (crcf 256 taps) to 10x (rrrf / cccf) faster on long blocks, equal to f32 rounding.
+// With the pipeline on (set_pipeline; StreamPipe) a block call of at least L samples runs on one of the object's two
+// lanes and reads its window from the tail of the previous call's input.
 template <class K>
 int FirFilt<K>::block_dev(const T *x, size_t n, T *y) {
-    YG_TRY(w.ensure_dev(st));
-    if (n == 0) return YAGI_OK;
+    if (n == 0) return w.ensure_dev(st);
+    const bool piped = w.can_pipe(n) && (kernel_choice != 4 || conv_ready);
+    hipStream_t s = st;
+    const T *win = nullptr;
+    if (piped) YG_TRY(w.begin_piped(st, &s, &win));
+    else { YG_TRY(w.ensure_dev(st)); win = w.dev(); }
+    T *wnext = piped ? nullptr : w.next();
     w.npush += n;
     const bool conv = kernel_choice == 4 && L <= 2049;
     if (conv) {
         YG_TRY(prepare_conv());
         if constexpr (K::id == 0)
-            YG_TRY(launch_fir_rrrf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
+            YG_TRY(launch_fir_rrrf_fftconv(win, x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, s, wnext));
         else
-            YG_TRY(launch_fir_cccf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
-        w.flip();                                   // the kernel's last workgroup wrote the next window
-        return YAGI_OK;
+            YG_TRY(launch_fir_cccf_fftconv(win, x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, s, wnext));
+    } else {
+        YG_TRY((launch_fir_block<K>(win, x, taps.template as<C>(), L, 1, scale, y, n, s, 0, wnext)));
     }
-    YG_TRY((launch_fir_block<K>(w.dev(), x, taps.template as<C>(), L, 1, scale, y, n, st, 0, w.next())));
+    if (piped) return w.finish_piped(x, n);
     w.flip();                                       // the kernel's last workgroup wrote the next window
     return YAGI_OK;
 }
 template <>
 int FirFilt<CRCF>::block_dev(const cf32 *x, size_t n, cf32 *y) {
-    YG_TRY(w.ensure_dev(st));
-    if (n == 0) return YAGI_OK;
-    w.npush += n;
+    if (n == 0) return w.ensure_dev(st);
     const bool conv = kernel_choice == 4 && L <= 2049;
     // auto: the matrix-pipe Toeplitz form where it exists (<= 256 taps) and the block fills the chip -- the same sums as
     // the sliding vector form (both exact on integer data), but the vector form runs into the chip's power cap on
-    // random data (0.63 of the FP32 peak, 0.80 on all-zero input) and the matrix form does not (0.72 either way:
+    // random data (0.63 of the FP32 peak, 0.80 on all-zero input) and the matrix form does not (0.79 either way:
     // profiles/r03_notes.md); else the register-sliding vector form
     const bool mfma = Lm && (kernel_choice == 3 || (kernel_choice == 0 && n >= ((size_t)1 << 16)));
     const bool slide = (kernel_choice == 2) || (kernel_choice == 0 && Lp <= kSlideMaxTaps && n >= 1024);
+    const bool piped = w.can_pipe(n) && (!conv || conv_ready);
+    hipStream_t s = st;
+    const cf32 *win = nullptr;
+    if (piped) YG_TRY(w.begin_piped(st, &s, &win));
+    else { YG_TRY(w.ensure_dev(st)); win = w.dev(); }
+    cf32 *wnext = piped ? nullptr : w.next();
+    w.npush += n;
     if (conv) {
         YG_TRY(prepare_conv());
-        YG_TRY(launch_fir_crcf_fftconv(w.dev(), x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, st, w.next()));
-        w.flip();
-        return YAGI_OK;
+        YG_TRY(launch_fir_crcf_fftconv(win, x, 0, n, hfreq.as<cf32>(), scale, L, twf.as<cf32>(), twb.as<cf32>(), y, n, s, wnext));
     } else if (mfma) {
-        YG_TRY(launch_fir_crcf_mfma(w.dev(), x, apack.as<float>(), L, Lm, scale, y, n, st, w.next()));
-        w.flip();
-        return YAGI_OK;
+        YG_TRY(launch_fir_crcf_mfma(win, x, apack.as<float>(), L, Lm, scale, y, n, s, wnext));
     } else if (slide && Lp <= kSlideMaxTaps) {
-        YG_TRY(launch_fir_crcf_slide(w.dev(), x, taps_pad.as<float>(), L, Lp, scale, y, n, st, w.next()));
-        w.flip();                                   // the kernel's last workgroup wrote the next window
-        return YAGI_OK;
+        YG_TRY(launch_fir_crcf_slide(win, x, taps_pad.as<float>(), L, Lp, scale, y, n, s, wnext));
     } else {
-        YG_TRY((launch_fir_block<CRCF>(w.dev(), x, taps.as<float>(), L, 1, scale, y, n, st, 0, w.next())));
-        w.flip();
-        return YAGI_OK;
+        YG_TRY((launch_fir_block<CRCF>(win, x, taps.as<float>(), L, 1, scale, y, n, s, 0, wnext)));
     }
-    return w.advance(x, n, st);
+    if (piped) return w.finish_piped(x, n);
+    w.flip();                                       // the kernel's last workgroup wrote the next window
+    return YAGI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,7 +638,7 @@ template <class K>
 int FirFilt<K>::prepare_conv() {
     if (conv_ready) return YAGI_OK;
     if (L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution needs <= 2049 taps");
-    YG_TRY(make_twiddles(4096, YAGI_FFT_FORWARD, twf));
+    YG_TRY(make_stream_twiddles(twf));      // W_4096 forward table + the lane-indexed rows of the table-twiddle transform
     YG_TRY(make_twiddles(4096, YAGI_FFT_BACKWARD, twb));
     // FFT_4096{[h; 0]} evaluated in double on the host (L x 4096 terms, once per tap set), rounded once
     {
@@ -614,37 +690,6 @@ int FirFilt<K>::prepare_conv() {
 // ---------------------------------------------------------------------------------------------
 // fused firfilt_crcf -> FFT stream
 // ---------------------------------------------------------------------------------------------
-// Pipelined block calls (yagi_hip_firfft_crcf_set_pipeline).  Consecutive blocks of the stream depend on each other
-// only through the L-sample filter window, and that window is INPUT data (the previous block's last L samples), which
-// the pipelined contract keeps intact until the join: block b + 1 reads it straight from the previous call's x, so it
-// needs nothing block b computes.  The block kernels alternate between two streams owned by the handle; call b does
-//     caller's stream: record `in`           lane b & 1: wait(in), block kernel b, record done[b & 1]
-// so block b + 1 ramps up while block b drains (on one stream every kernel waits for the complete drain of the one
-// before it: ~4 us of a 61 us block).  The caller's stream is NOT made to wait per call (its next `in` would inherit
-// that wait and serialise the blocks); it joins the lanes in yagi_hip_firfft_crcf_join, which every other entry point
-// of the object calls first and which also copies the last block's tail into the object's window.
-struct StreamPipe {
-    bool on = false;
-    hipStream_t lane[2] = {nullptr, nullptr};
-    hipEvent_t in = nullptr, done[2] = {nullptr, nullptr};
-    bool busy[2] = {false, false};
-    unsigned calls = 0;
-    const cf32 *prev_tail = nullptr;      // last L samples of the previous pipelined block (null: use the object's window)
-    int init() {
-        if (lane[0]) return YAGI_OK;
-        for (auto &s : lane) YG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        YG_HIP(hipEventCreateWithFlags(&in, hipEventDisableTiming));
-        for (auto &e : done) YG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        return YAGI_OK;
-    }
-    ~StreamPipe() {
-        for (auto &s : lane)
-            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-        if (in) (void)hipEventDestroy(in);
-        for (auto &e : done) if (e) (void)hipEventDestroy(e);
-    }
-};
-
 struct FirFft {
     FirFilt<CRCF> fir;
     size_t nfft = 0;
@@ -653,20 +698,7 @@ struct FirFft {
     int variant = 0;
     DevBuf xin, yout;
     DevBuf scratch;            // variant 3: the FIR output stream between the two kernels
-    StreamPipe pipe;
-    // the caller's stream waits for every block handed to the lanes, then takes over the filter window
-    int join() {
-        for (int i = 0; i < 2; ++i) {
-            if (pipe.busy[i]) YG_HIP(hipStreamWaitEvent(fir.st, pipe.done[i], 0));
-            pipe.busy[i] = false;
-        }
-        if (pipe.prev_tail) {
-            YG_TRY(launch_update_window<cf32>(fir.w.dev(), pipe.prev_tail, (size_t)fir.L, fir.L, fir.w.next(), fir.st));
-            fir.w.flip();
-            pipe.prev_tail = nullptr;
-        }
-        return YAGI_OK;
-    }
+    int join() { return fir.w.join(fir.st); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -834,8 +866,13 @@ static int firfilt_block_host(FirFilt<K> *q, const typename K::T *x, size_t nx, 
     CHECK_PTR(y);
     YG_TRY(q->ws.x.ensure(nx * sizeof(T)));
     YG_TRY(q->ws.y.ensure(nx * sizeof(T)));
+    YG_TRY(q->w.join(q->st));                            // the workspace is reused: host-pointer calls never pipeline
     YG_TRY(upload(q->ws.x.p, x, nx * sizeof(T), q->st));
-    YG_TRY(q->block_dev(q->ws.x.template as<T>(), nx, q->ws.y.template as<T>()));
+    const bool was = q->w.pipe.on;
+    q->w.pipe.on = false;
+    const int rc = q->block_dev(q->ws.x.template as<T>(), nx, q->ws.y.template as<T>());
+    q->w.pipe.on = was;
+    YG_TRY(rc);
     return download(y, q->ws.y.p, nx * sizeof(T), q->st);
 }
 
@@ -987,13 +1024,26 @@ static int taps_groupdelay(const std::vector<C> &h, float fc, float *out) {
     int yagi_hip_firfilt_##K##_set_stream(yagi_hip_firfilt_##K q, yagi_stream_t s) try {            \
         CHECK_Q(q);                                                                                 \
         if (q->st == to_stream(s)) return YAGI_OK;                                                  \
+        YG_TRY(q->w.join(q->st));                                                                   \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         q->st = to_stream(s);                                                                       \
         return YAGI_OK;                                                                             \
     } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_set_pipeline(yagi_hip_firfilt_##K q, int on) try {                   \
+        CHECK_Q(q);                                                                                 \
+        YG_TRY(q->w.join(q->st));                                                                   \
+        if (on) YG_TRY(q->w.pipe.init());                                                           \
+        q->w.pipe.on = on != 0;                                                                     \
+        return YAGI_OK;                                                                             \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
+    int yagi_hip_firfilt_##K##_join(yagi_hip_firfilt_##K q) try {                                   \
+        CHECK_Q(q);                                                                                 \
+        return q->w.join(q->st);                                                                    \
+    } catch (...) { return ::yagi::api_exception(); }                                               \
     int yagi_hip_firfilt_##K##_set_coefficients(yagi_hip_firfilt_##K q, const C *h, size_t n) try { \
         CHECK_Q(q);                                                                                 \
         if (n && !h) return fail(YAGI_ERR_CONFIG, "null pointer argument");                         \
+        YG_TRY(q->w.join(q->st));                                                                   \
         YG_HIP(hipStreamSynchronize(q->st));                                                        \
         const bool resize = (n != (size_t)q->L);                                                    \
         YG_TRY(q->load_taps(h, n));                                                                 \
@@ -2253,8 +2303,8 @@ int yagi_hip_firfft_crcf_destroy(yagi_hip_firfft_crcf q) try { delete q; return 
 int yagi_hip_firfft_crcf_set_pipeline(yagi_hip_firfft_crcf q, int on) try {
     CHECK_Q(q);
     YG_TRY(q->join());
-    if (on) YG_TRY(q->pipe.init());
-    q->pipe.on = on != 0;
+    if (on) YG_TRY(q->fir.w.pipe.init());
+    q->fir.w.pipe.on = on != 0;
     return YAGI_OK;
 } catch (...) { return ::yagi::api_exception(); }
 int yagi_hip_firfft_crcf_join(yagi_hip_firfft_crcf q) try {
@@ -2296,10 +2346,9 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     CHECK_NOALIAS(x, nframes * q->nfft, spectra, nframes * q->nfft);
     auto &f = q->fir;
     const bool use_freq = q->nfft == 4096 && (q->variant == 4 || (q->variant == 0 && f.L <= 257));
-    const bool piped = q->pipe.on && use_freq && f.w.dev_valid && f.conv_ready && f.hfreq_s_valid &&
+    const bool piped = use_freq && f.w.can_pipe(nframes * q->nfft) && f.conv_ready && f.hfreq_s_valid &&
                        f.hfreq_s_scale == f.scale;
-    if (!piped) YG_TRY(q->join());        // everything below runs on the caller's stream
-    YG_TRY(f.w.ensure_dev(f.st));
+    if (!piped) YG_TRY(f.w.ensure_dev(f.st));   // joins the lanes: everything below runs on the caller's stream
     // auto (0): fast convolution once the filter is long enough for it to win (measured crossover ~100 taps:
     // the direct kernels cost ~0.65 us per tap and 2^24 samples, the convolution kernel a flat 88 us)
     if (q->nfft != 4096) {     // other frame lengths: overlap-save FIR into a scratch stream, then the batched transform
@@ -2314,19 +2363,13 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
     }
     if (piped) {
         // the frequency-domain kernel on lane b & 1 (see StreamPipe); tables and scaled FFT{h} are in place
-        auto &p = q->pipe;
-        const int i = (int)(p.calls & 1u);
         const size_t n = nframes * q->nfft;
-        YG_HIP(hipEventRecord(p.in, f.st));
-        YG_HIP(hipStreamWaitEvent(p.lane[i], p.in, 0));
-        YG_TRY(launch_firfft_crcf_4096_freq(p.prev_tail ? p.prev_tail : f.w.dev(), x, f.hfreq_s.as<cf32>(),
-                                            f.gfft_s.as<cf32>(), f.L, q->tw.as<cf32>(), spectra, nullptr, nframes,
-                                            p.lane[i]));
-        YG_HIP(hipEventRecord(p.done[i], p.lane[i]));
-        p.busy[i] = true;
-        ++p.calls;
-        p.prev_tail = x + (n - (size_t)f.L);       // n >= 4096 > L
-        return YAGI_OK;
+        hipStream_t lane;
+        const cf32 *win;
+        YG_TRY(f.w.begin_piped(f.st, &lane, &win));
+        YG_TRY(launch_firfft_crcf_4096_freq(win, x, f.hfreq_s.as<cf32>(), f.gfft_s.as<cf32>(), f.L, q->tw.as<cf32>(), spectra,
+                                            nullptr, nframes, lane));
+        return f.w.finish_piped(x, n);
     }
     if (use_freq) {
         // frequency-domain form (one kernel, 16 B/sample): FFT{h}.FFT{x_f} + FFT{frame-boundary correction}

@@ -75,6 +75,16 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
         : "=&v"(r) : "v"(tov(a)), "v"(tov(w)));
     return f2(r);
 }
+// a * conj(w)
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r) : "v"(tov(a)), "v"(tov(w)));
+    return f2(r);
+}
+template <int SIGN>
+__device__ __forceinline__ float2 cmul_dir(float2 a, float2 w) { return SIGN < 0 ? cmul(a, w) : cmul_conj(a, w); }
 // a * k, k wave-uniform (compile-time constants: lives in an SGPR pair)
 __device__ __forceinline__ float2 cmul_k(float2 a, float2 k) {
     v2f r;

@@ -211,4 +211,57 @@ __device__ __forceinline__ void fft4096_passes_to_regs(float2 (&v)[16], float2 *
     fft4096_pass23_to_regs<SIGN, TWP>(v, lds, tw);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same three passes with the twiddle scheme of the headline kernel (freq_kernels.hip), either direction:
+//   pass 1  W_4096^{tc}: four exact entries W^{t 2^k} from lane-indexed table rows (coalesced loads) + products;
+//   pass 2  W_256^{b'c'} = T[b'][c'] from a 16 x 16 table in LDS (row pitch 17: immediate-offset ds_reads, no gathers).
+// `ax` = the auxiliary rows behind the W_4096 table of make_stream_twiddles (capi.hip): rows 0-3 W^{t 2^k}, row 5
+// W_256^{(t&15)(t>>4)} (the T table's source), FORWARD values -- the inverse direction multiplies by their conjugates.
+// fft4096_tab_load fills T (call once per workgroup; a barrier must follow before T is read).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned kTRow = 17;
+constexpr unsigned kFft4096TabFloat2 = 16 * kTRow;
+__device__ __forceinline__ void fft4096_tab_load(float2 *__restrict__ T, const float2 *__restrict__ ax) {
+    const unsigned t = threadIdx.x;
+    T[(t >> 4) * kTRow + (t & 15u)] = ax[1280 + t];
+}
+template <int SIGN>
+__device__ __forceinline__ void fft4096_tab_to_regs(float2 (&v)[16], float2 *__restrict__ lds, const float2 *__restrict__ T,
+                                                    const float2 *__restrict__ ax) {
+    const unsigned t = threadIdx.x;
+    dft16<SIGN>(v);
+    {
+        float2 w[16];
+        twiddle_powers_from(w, ax[t], ax[256 + t], ax[512 + t], ax[768 + t]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 z = v[dft16_pos(c)];
+            if (c) z = cmul_dir<SIGN>(z, w[c]);
+            lds[c * kEx1Stride + t] = z;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned c = t >> 4, bp = t & 15;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = lds[c * kEx1Stride + 16 * a + bp];
+        __syncthreads();
+        dft16<SIGN>(v);
+#pragma unroll
+        for (int cp = 0; cp < 16; ++cp) {
+            float2 u = v[dft16_pos(cp)];
+            if (cp) u = cmul_dir<SIGN>(u, T[bp * kTRow + cp]);
+            lds[bp * kEx2Stride + cp * 16 + c] = u;
+        }
+    }
+    __syncthreads();
+    float2 w[16];
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) w[bp] = lds[bp * kEx2Stride + t];
+    dft16<SIGN>(w);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) v[d] = w[dft16_pos(d)];
+    __syncthreads();
+}
+
 }  // namespace yagi

@@ -56,7 +56,6 @@ namespace yagi {
 constexpr int kFreqMaxTaps = 257;
 constexpr unsigned kOffCvs = kFft4096LdsFloat2;          // c_f, 256 float2 (behind the exchange buffer)
 constexpr unsigned kOffT256 = kOffCvs + 256;             // T[b][c] = W_256^{bc}, 16 rows of 17 float2
-constexpr unsigned kTRow = 17;
 constexpr unsigned kFreqLdsFloat2 = kOffT256 + 16 * kTRow;   // 39 040 B -> 4 workgroups per CU
 
 // passes 2 and 3 of the frame transform (exchange-1 data stored, a barrier ago), pass-2 twiddles W_256^{b'c'} = T[b'][c']
@@ -129,16 +128,6 @@ __device__ __forceinline__ void freq_head256(const float2 *__restrict__ xs, floa
 // ---------------------------------------------------------------------------------------------
 template <int SIGN>
 __device__ __forceinline__ float2 w8(float c, float s) { return make_float2(c, SIGN < 0 ? -s : s); }
-// a * conj(w)
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w) {
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
-        : "=&v"(r) : "v"(tov(a)), "v"(tov(w)));
-    return f2(r);
-}
-template <int SIGN>
-__device__ __forceinline__ float2 cmul_dir(float2 a, float2 w) { return SIGN < 0 ? cmul(a, w) : cmul_conj(a, w); }
 // X[k] = E[k & 3] + W_8^k O[k & 3]; E / O = 4-point transforms of the even / odd inputs (natural order)
 template <int SIGN, int NOUT>
 __device__ __forceinline__ void dft8_combine(const float2 (&E)[4], float2 (&O)[4], float2 (&X)[8]) {

@@ -633,35 +633,39 @@ __device__ __forceinline__ T conv_fetch(const T *__restrict__ win, const T *__re
 template <int KIND>
 __global__ void __launch_bounds__(256)
 firfilt_fftconv_kernel(const void *__restrict__ win_, const void *__restrict__ x_, long long pre,
-                       long long x_avail, const float2 *__restrict__ hs, float2 sc, int L, int V,
-                       const float2 *__restrict__ twf, const float2 *__restrict__ twb,
+                       long long x_avail, const float2 *__restrict__ hs, float2 sc, int L, int V, int P0,
+                       const float2 *__restrict__ tws,
                        void *__restrict__ y_, size_t ny, void *__restrict__ win_next_) {
     constexpr bool REAL = KIND == kConvRrrf;
-    using T = typename std::conditional<REAL, float, float2>::type;
-    const T *win = static_cast<const T *>(win_), *x = static_cast<const T *>(x_);
-    T *y = static_cast<T *>(y_);
+    using T_ = typename std::conditional<REAL, float, float2>::type;
+    const T_ *win = static_cast<const T_ *>(win_), *x = static_cast<const T_ *>(x_);
+    T_ *y = static_cast<T_ *>(y_);
     // the last workgroup also writes the filter window after this call: the last L samples of win ++ x[0, x_avail)
     // (saves the separate update launch; win_next may be null)
     if (win_next_ && blockIdx.x == gridDim.x - 1) {
-        T *wn = static_cast<T *>(win_next_);
+        T_ *wn = static_cast<T_ *>(win_next_);
         for (int j = threadIdx.x; j < L; j += 256) {
             const long long c = x_avail + j;                     // index into win ++ x
             wn[j] = (c < (long long)L) ? win[c] : x[c - L];
         }
     }
-    __shared__ float2 lds[kFft4096LdsFloat2];
+    __shared__ float2 lds[kFft4096LdsFloat2 + kFft4096TabFloat2];           // 36 992 B: four workgroups per CU
+    float2 *T = lds + kFft4096LdsFloat2;
+    const float2 *ax = tws + 4096;
     const size_t k0 = (REAL ? 2 : 1) * (size_t)blockIdx.x;            // first conv block of this workgroup
-    const long long base = (long long)k0 * V - (L - 1);
+    const long long base = (long long)k0 * V - P0;      // P0 = 4096 - V >= L - 1 samples of history lead every block
     const long long last = base + (REAL ? V : 0) + 4096;              // end of the (second) block's input
     const bool interior = base >= -pre && last <= x_avail && (k0 + (REAL ? 2 : 1)) * (size_t)V <= ny;
     float2 v[16];
     if (interior) {
-        const T *src = x + base;                     // block-uniform base (SGPRs) + 32-bit lane offset
+        const T_ *src = x + base;                    // block-uniform base (SGPRs) + 32-bit lane offset
 #pragma unroll
         for (unsigned a = 0; a < 16; ++a) {
-            if constexpr (REAL) v[a] = make_float2(src[256u * a + threadIdx.x], src[V + 256u * a + threadIdx.x]);
-            else v[a] = src[256u * a + threadIdx.x];
+            if constexpr (REAL) v[a] = make_float2(ld_stream(src + 256u * a + threadIdx.x), ld_stream(src + V + 256u * a + threadIdx.x));
+            else v[a] = ld_stream(src + 256u * a + threadIdx.x);
         }
+        fft4096_tab_load(T, ax);
+        __syncthreads();
     } else {
         for (int i = threadIdx.x; i < 4096; i += 256) {
             if constexpr (REAL)
@@ -670,38 +674,45 @@ firfilt_fftconv_kernel(const void *__restrict__ win_, const void *__restrict__ x
             else
                 lds[i] = conv_fetch(win, x, base + i, pre, x_avail, L);
         }
+        fft4096_tab_load(T, ax);
         __syncthreads();
 #pragma unroll
         for (unsigned a = 0; a < 16; ++a) v[a] = lds[256u * a + threadIdx.x];
         __syncthreads();
     }
-#ifndef YG_CONV_TWP
-#define YG_CONV_TWP true
-#endif
-    // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again
-    fft4096_passes_to_regs<-1, YG_CONV_TWP>(v, lds, twf);
+    // forward transform: pass 3 leaves bin t + 256 d in v[d], which is the pass-1 input layout again.  Twiddles as in
+    // the headline kernel (fft_core.hpp fft4096_tab_to_regs): W_256 powers from a table in LDS, the W_4096 set from
+    // four coalesced row entries + products -- the plain form gathered four table entries per lane and pass, twice per
+    // transform, and the L1 / address path was what the kernel waited for
+    fft4096_tab_to_regs<-1>(v, lds, T, ax);
+    {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(hs, 32768u);
+        float2 hv[16];
 #pragma unroll
-    for (unsigned d = 0; d < 16; ++d) {
-        const float2 p = cmul(v[d], hs[threadIdx.x + 256u * d]);
-        if constexpr (KIND == kConvCccf) v[d] = cmul(p, sc);
-        else v[d] = cscale(p, sc.x);
+        for (unsigned d = 0; d < 16; ++d) hv[d] = buf_ld_aux<0>(rh, 8u * threadIdx.x, 2048u * d);     // a table: cached
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) {
+            const float2 p = cmul(v[d], hv[d]);
+            if constexpr (KIND == kConvCccf) v[d] = cmul(p, sc);
+            else v[d] = cscale(p, sc.x);
+        }
     }
-    fft4096_passes_to_regs<+1, YG_CONV_TWP>(v, lds, twb);
-    // time sample n = t + 256 d of the block; valid ones are n >= L-1  ->  y[V*k + n - (L-1)]
+    fft4096_tab_to_regs<+1>(v, lds, T, ax);
+    // time sample n = t + 256 d of the block; valid ones are n >= P0  ->  y[V*k + n - P0]
     const size_t o0 = k0 * (size_t)V;
     const size_t left = ny > o0 ? ny - o0 : 0;                         // outputs from o0 to the end of y
     const size_t lim0 = interior ? (size_t)V : (left < (size_t)V ? left : (size_t)V);
-    T *yb = y + o0 - (size_t)(L - 1);                // yb[n], n = t + 256 d >= L-1
+    T_ *yb = y + o0 - (size_t)P0;                     // yb[n], n = t + 256 d >= P0
 #pragma unroll
     for (unsigned d = 0; d < 16; ++d) {
         const unsigned n = threadIdx.x + 256u * d;
-        if (n < (unsigned)(L - 1)) continue;
-        const size_t j = n - (unsigned)(L - 1);
+        if (n < (unsigned)P0) continue;
+        const size_t j = n - (unsigned)P0;
         if constexpr (REAL) {
-            if (j < lim0) yb[n] = v[d].x;
-            if (interior || j + (size_t)V < left) yb[(size_t)V + n] = v[d].y;
+            if (j < lim0) st_stream(yb + n, v[d].x);
+            if (interior || j + (size_t)V < left) st_stream(yb + (size_t)V + n, v[d].y);
         } else {
-            if (j < lim0) yb[n] = v[d];
+            if (j < lim0) st_stream(yb + n, v[d]);
         }
     }
 }
@@ -711,14 +722,19 @@ static int launch_fir_fftconv_t(const T *win, const T *x, size_t pre, size_t x_a
                                 int L, const cf32 *twf, const cf32 *twb, T *y, size_t ny, hipStream_t st, T *win_next) {
     if (ny == 0) return YAGI_OK;
     if (L < 1 || L > 2049) return fail(YAGI_ERR_CONFIG, "fast convolution kernel needs 1..2049 taps (got %d)", L);
-    const int V = 4096 - (L - 1);
+    // outputs per block: what a 4096-point block leaves after the L - 1 samples of history, rounded down to whole
+    // 128-byte lines, so that with line-aligned x and y every block's loads and stores are whole lines (V = 3840
+    // instead of 3841 at 256 taps: the blocks started 8 bytes before a line and every wave access touched five lines)
+    const int align = 128 / (int)sizeof(T);
+    const int V = (4096 - (L - 1)) / align * align > 0 ? (4096 - (L - 1)) / align * align : 4096 - (L - 1);
+    const int P0 = 4096 - V;
     const size_t nblk = (ny + V - 1) / V;
     const size_t nwg = KIND == kConvRrrf ? (nblk + 1) / 2 : nblk;
     if (nwg > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
     firfilt_fftconv_kernel<KIND><<<(unsigned)nwg, 256, 0, st>>>(
         win, x, (long long)pre, (long long)x_avail, reinterpret_cast<const float2 *>(hs),
-        make_float2(scale.re / 4096.0f, scale.im / 4096.0f), L, V, reinterpret_cast<const float2 *>(twf),
-        reinterpret_cast<const float2 *>(twb), y, ny, win_next);
+        make_float2(scale.re / 4096.0f, scale.im / 4096.0f), L, V, P0, reinterpret_cast<const float2 *>(twf), y, ny, win_next);
+    (void)twb;
     YG_LAUNCH_CHECK();
     return YAGI_OK;
 }
