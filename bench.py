@@ -389,6 +389,26 @@ def main():
         except Exception as e:
             extras["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
 
+        # (1c) the same kernel through plain block calls on ONE stream: every launch then waits for the complete drain
+        # of the one before it, and rocprofv3's mean launch duration IS the launch-to-launch time (with the pipelined
+        # calls of `value` two launches are in flight at a time: a launch lasts ~1.7x the launch-to-launch time)
+        if pipelined:
+            qp = ya.FirFftStream(h, NFFT)
+            qp.set_scale(scale)
+            qp.set_variant(args.variant)
+            qp.set_stream(stream.cuda_stream)
+
+            def run_plain():
+                for xb, yb in blocks:
+                    qp.execute_dev(xb, nframes, yb)
+            run_plain()
+            p_ms = timed(run_plain, reps, stream) / nb
+            extras["plain_block_calls"] = {
+                "what": "the same stream and kernel, execute_dev without set_pipeline (one stream, launches back to back); "
+                        "NOT the value of this line",
+                "ms_per_block": round(p_ms, 5), "value": round(n / p_ms / 1e3, 1), "unit": "Msamples/s",
+                "frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n / p_ms / 1e6 / HBM_PEAK_GBS, 4)}
+
         # (2) the same stream through the other algorithms
         def time_variant(v):
             qd = ya.FirFftStream(h, NFFT)
@@ -584,7 +604,10 @@ def main():
                          "note": {3: "fast convolution: overlap-save FIR kernel + batched FFT, FIR output stream "
                                      "crosses HBM once; kernel_ms = both launches of a block",
                                   4: "one launch per 2^24-sample block; the stream is read once and the spectra "
-                                     "written once; kernel_ms = timed region / launches (back-to-back launches)"
+                                     "written once; kernel_ms = timed region / launches = launch-to-launch time.  With "
+                                     "the pipelined block calls two launches are in flight at a time (each lasts ~1.7x "
+                                     "kernel_ms in a rocprofv3 trace; profiles/r03_bench_span.txt derives the same "
+                                     "launch-to-launch time from the trace); `plain_block_calls` is the one-stream form"
                                   }.get(eff_variant, "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32"),
                          "fp32": {"achieved_tflops": round(flop_per_sample * n / kern_s / 1e12, 2),
                                   "peak_tflops": FP32_PEAK_TFLOPS, "flop_per_sample": flop_per_sample,
