@@ -195,7 +195,7 @@ def main():
                          "gloo lets several ranks share one GPU when rehearsing the N>1 path on a 1-GPU box)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="headline through plain block calls on one stream instead of the pipelined calls "
-                         "(yagi_hip_firfft_crcf_set_pipeline: consecutive blocks overlap on two streams of the object)")
+                         "(yagi_hip_firfft_crcf_set_pipeline: consecutive blocks overlap on three streams of the object)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -391,7 +391,7 @@ def main():
 
         # (1c) the same kernel through plain block calls on ONE stream: every launch then waits for the complete drain
         # of the one before it, and rocprofv3's mean launch duration IS the launch-to-launch time (with the pipelined
-        # calls of `value` two launches are in flight at a time: a launch lasts ~1.7x the launch-to-launch time)
+        # calls of `value` about two launches are in flight at a time: a launch lasts ~1.7x the launch-to-launch time)
         if pipelined:
             qp = ya.FirFftStream(h, NFFT)
             qp.set_scale(scale)
@@ -589,7 +589,7 @@ def main():
                        "samples_per_step_per_gpu": ntot, "blocks_per_step": nb, "samples_per_block": n,
                        "frames_per_block": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
-                       "block_calls": "pipelined (set_pipeline: consecutive execute_dev calls alternate between two "
+                       "block_calls": "pipelined (set_pipeline: consecutive execute_dev calls rotate over three "
                                       "streams of the object, joined into the launch stream once per step)"
                                       if pipelined else "plain (one stream)",
                        "kernel": kernel_name, "variant": args.variant, "prewarm_ms": args.prewarm_ms},
@@ -605,7 +605,7 @@ def main():
                                      "crosses HBM once; kernel_ms = both launches of a block",
                                   4: "one launch per 2^24-sample block; the stream is read once and the spectra "
                                      "written once; kernel_ms = timed region / launches = launch-to-launch time.  With "
-                                     "the pipelined block calls two launches are in flight at a time (each lasts ~1.7x "
+                                     "the pipelined block calls about two launches are in flight at a time (each lasts ~1.7x "
                                      "kernel_ms in a rocprofv3 trace; profiles/r03_bench_span.txt derives the same "
                                      "launch-to-launch time from the trace); `plain_block_calls` is the one-stream form"
                                   }.get(eff_variant, "direct-form 256-tap crcf is FP32-ALU bound (64 flop/B); see fp32"),

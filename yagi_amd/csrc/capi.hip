@@ -57,17 +57,20 @@ static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
 // Pipelined block calls (yagi_hip_firfft_crcf_set_pipeline, yagi_hip_firfilt_*_set_pipeline).  Consecutive blocks of the stream depend on each other
 // only through the L-sample filter window, and that window is INPUT data (the previous block's last L samples), which
 // the pipelined contract keeps intact until the join: block b + 1 reads it straight from the previous call's x, so it
-// needs nothing block b computes.  The block kernels alternate between two streams owned by the handle; call b does
-//     caller's stream: record `in`           lane b & 1: wait(in), block kernel b, record done[b & 1]
+// needs nothing block b computes.  The block kernels rotate over three streams (lanes) owned by the handle; call b does
+//     caller's stream: record `in`           lane b % 3: wait(in), block kernel b, record done[b % 3]
 // so block b + 1 ramps up while block b drains (on one stream every kernel waits for the complete drain of the one
 // before it: ~4 us of a 61 us block).  The caller's stream is NOT made to wait per call (its next `in` would inherit
 // that wait and serialise the blocks); it joins the lanes in *_join (DevWindow::join), which every other use of the
 // object's window goes through first and which also copies the last block's tail into the object's window.
 struct StreamPipe {
     bool on = false;
-    hipStream_t lane[2] = {nullptr, nullptr};
-    hipEvent_t in = nullptr, done[2] = {nullptr, nullptr};
-    bool busy[2] = {false, false};
+    // three lanes: 55.5 us per block of the headline stream against 56.2 with two and 60.6 with four (the device exposes
+    // four hardware queues and the caller's stream is one of them): tools/ab_libs.py, profiles/r03_notes.md
+    static constexpr int kLanes = 3;
+    hipStream_t lane[kLanes] = {};
+    hipEvent_t in = nullptr, done[kLanes] = {};
+    bool busy[kLanes] = {};
     unsigned calls = 0;
     const void *prev_tail = nullptr;      // last L samples of the previous pipelined block (null: use the object's window)
     int init() {
@@ -110,7 +113,7 @@ struct DevWindow {
     // the caller's stream waits for every block handed to the lanes, then takes over the filter window (the last block's
     // tail); every other access to the window comes through here first
     int join(hipStream_t st) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < StreamPipe::kLanes; ++i) {
             if (pipe.busy[i]) YG_HIP(hipStreamWaitEvent(st, pipe.done[i], 0));
             pipe.busy[i] = false;
         }
@@ -124,7 +127,7 @@ struct DevWindow {
     // one pipelined block: the caller's stream records `in`, lane (calls & 1) waits for it; returns the lane and the
     // window the block kernel reads.  finish_piped() after the launch.
     int begin_piped(hipStream_t st, hipStream_t *lane, const T **win) {
-        const int i = (int)(pipe.calls & 1u);
+        const int i = (int)(pipe.calls % (unsigned)StreamPipe::kLanes);
         YG_HIP(hipEventRecord(pipe.in, st));
         YG_HIP(hipStreamWaitEvent(pipe.lane[i], pipe.in, 0));
         *lane = pipe.lane[i];
@@ -132,7 +135,7 @@ struct DevWindow {
         return YAGI_OK;
     }
     int finish_piped(const T *x, size_t n) {          // n >= len
-        const int i = (int)(pipe.calls & 1u);
+        const int i = (int)(pipe.calls % (unsigned)StreamPipe::kLanes);
         YG_HIP(hipEventRecord(pipe.done[i], pipe.lane[i]));
         pipe.busy[i] = true;
         ++pipe.calls;
@@ -2362,7 +2365,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         return f.w.advance(x, n, f.st);
     }
     if (piped) {
-        // the frequency-domain kernel on lane b & 1 (see StreamPipe); tables and scaled FFT{h} are in place
+        // the frequency-domain kernel on lane b % 3 (see StreamPipe); tables and scaled FFT{h} are in place
         const size_t n = nframes * q->nfft;
         hipStream_t lane;
         const cf32 *win;
