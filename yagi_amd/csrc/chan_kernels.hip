@@ -186,9 +186,7 @@ __device__ __forceinline__ void chan_write_next_hist(const float2 *__restrict__ 
 __host__ __device__ constexpr int col_pitch(int M, int nq) { return M + (nq <= 32 ? 32 / nq : 1); }
 constexpr int kColTile = 16;
 constexpr int kColHalf = 8;
-#ifndef YG_COL_WGS
-#define YG_COL_WGS 1024
-#endif
+constexpr size_t kColWgs = 1024;               // workgroups a launch aims for: four per CU
 
 // M = 2^LGM is a template parameter so that only the two radix passes M needs are instantiated (with a run-time
 // plan the register allocation is that of the widest radix: 200 VGPRs).
@@ -315,7 +313,7 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
     // >= ~2048 workgroups
-    size_t run = nframes / ((size_t)YG_COL_WGS * G);
+    size_t run = nframes / (kColWgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 256) run = 256;
@@ -441,7 +439,7 @@ template <int P, int LGM>
 static int launch_firpfbch_wide(const cf32 *hist, const cf32 *x, const float *h, const cf32 *twM,
                                 cf32 *y, size_t nframes, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM, HF = 4096 / M, TILE = 2 * HF;
-    size_t run = nframes / (size_t)YG_COL_WGS;
+    size_t run = nframes / kColWgs;
     run = run / TILE * TILE;
     if (run < (size_t)TILE) run = TILE;
     if (run > 256) run = 256;
@@ -698,7 +696,7 @@ static int launch_firpfbch_syn_col(const cf32 *hist, const cf32 *x, const float 
                                    cf32 *y, size_t nframes, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
-    size_t run = nframes / ((size_t)YG_COL_WGS * G);
+    size_t run = nframes / (kColWgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 256) run = 256;
@@ -848,20 +846,6 @@ firpfbch2_kernel(const float2 *__restrict__ hist, int hist_len, const float2 *__
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifdef YG_STAMPS
-__device__ unsigned long long g_chan_stamps[2048 * 4 * 12];
-#define YG_CSTAMP(i)                                                                                     \
-    do {                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        unsigned long long ts_;                                                                          \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                      \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        if ((threadIdx.x & 63u) == 0 && blockIdx.x < 2048u && t == 2 * kColTile)                         \
-            g_chan_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 12u + (i)] = ts_;                      \
-    } while (0)
-#else
-#define YG_CSTAMP(i) do { } while (0)
-#endif
 // firpfbch2, column-sliding form (M in {64,128,256}, branch length P = 2m in {2,4,8}, even first step):
 // lane b owns window b.  A window is fed once per PAIR of steps (even steps feed b < M/2, odd steps feed
 // b >= M/2) and produces an output on both steps of the pair with two different tap sets
@@ -936,7 +920,6 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     float2 *yb = y + wg_first * Mr;
     auto half_tile = [&](float2 (&xin)[kPairs], int t, auto slot0) {
         constexpr int S0 = decltype(slot0)::value;                       // ring slot of the half tile's first pair
-        YG_CSTAMP(0);
 #pragma unroll
         for (int kk = 0; kk < kPairs; ++kk) {
             const float2 old = w[(S0 + kk) % P];
@@ -959,9 +942,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             va[(g * kColHalf + 2 * kk + 1) * pitch + b] = a1;
         }
         if (t + kColTile < run) load4(xin, t + kColTile);                 // in flight during the transforms
-        YG_CSTAMP(1);
         __syncthreads();
-        YG_CSTAMP(2);
         const float2 *res;
         if constexpr (SHARDED) {
             // fold to the rank's residue class: Z[b'] = W_M^{-b' r} sum_a W_R^{-a r} V[Mr*a + b']
@@ -981,9 +962,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
             res = lds_fft_pow2<+1, true>(vb, va, Mr, nq, plan, twl, R, true, pitch, lgnq);
         } else {
             stockham_pass<R0, +1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
-            YG_CSTAMP(3);
             __syncthreads();
-            YG_CSTAMP(4);
             res = vb;
             if constexpr (R1 >= 8 && M / R1 >= 16) {
                 // last pass straight from registers to y: 16-lane runs of 128 contiguous bytes (M = 256)
@@ -995,15 +974,11 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                     else if (t + sl < group_steps(gq))
                         yb[(size_t)(gq * run + t + sl) * M + k] = make_float2(v.x * invM, v.y * invM);
                 });
-                YG_CSTAMP(7);
-                YG_CSTAMP(8);
                 return;                          // no barrier: the next half tile writes va first, and its own
                                                  // barrier stands between this pass's reads of vb and the next writes
             } else if constexpr (R1 > 1) {
                 stockham_pass<R1, +1, true>(vb, va, M, R0, nq, twl, 1, true, pitch, lgnq);
-                YG_CSTAMP(5);
                 __syncthreads();
-                YG_CSTAMP(6);
                 res = va;
             }
         }
@@ -1019,9 +994,7 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
                 yb[(size_t)(gq * run + t + sl) * Mr + k] = make_float2(v.x * invM, v.y * invM);
             }
         }
-        YG_CSTAMP(7);
         __syncthreads();
-        YG_CSTAMP(8);
     };
     load4(xa, 0);
     load4(xb, kColHalf);
@@ -1037,7 +1010,7 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
                                 cf32 *hist_next, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
-    size_t run = nsteps / ((size_t)YG_COL_WGS * G);
+    size_t run = nsteps / (kColWgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 512) run = 512;
@@ -1188,7 +1161,7 @@ template <int P, int LGM>
 static int launch_firpfbch2_wide(const cf32 *hist, int hist_len, const cf32 *x, const float *h, const cf32 *twM,
                                  cf32 *y, size_t nsteps, hipStream_t st, int p_real) {
     constexpr int M = 1 << LGM, HS = 4096 / M, TILE = 2 * HS;
-    size_t run = nsteps / (size_t)YG_COL_WGS;
+    size_t run = nsteps / kColWgs;
     run = run / TILE * TILE;
     if (run < (size_t)TILE) run = TILE;
     if (run > 512) run = 512;
@@ -1432,7 +1405,7 @@ static int launch_firpfbch2_syn_col(const cf32 *hist, const cf32 *x, const float
                                     cf32 *y, size_t nsteps, hipStream_t st, int p2_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
-    size_t run = nsteps / ((size_t)YG_COL_WGS * G);
+    size_t run = nsteps / (kColWgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 256) run = 256;
@@ -1521,8 +1494,3 @@ int launch_firpfbch2_assemble(const cf32 *gathered, size_t nsteps, int M, int nr
 
 }  // namespace yagi
 
-#ifdef YG_STAMPS
-extern "C" int yagi_hip_debug_chan_stamps(unsigned long long *dst, size_t count) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(yagi::g_chan_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#endif

@@ -22,9 +22,7 @@
 
 namespace yagi {
 
-#ifndef YG_FUSED_TWP
-#define YG_FUSED_TWP true       // twiddles by products also in the fused kernels (at 4 waves/SIMD: 0.174 -> 0.167 ms)
-#endif
+constexpr bool kFusedTwp = true;           // twiddles by products also in the fused kernels (at 4 waves/SIMD: 0.174 -> 0.167 ms)
 constexpr int kTile = 4096;                 // outputs per workgroup (= FFT length when fused)
 constexpr int kRowPad = 17;                 // 16 samples + 1 pad
 
@@ -151,10 +149,7 @@ firfilt_crcf_slide_kernel(const float2 *__restrict__ win, const float2 *__restri
 }
 
 // ---- fused FIR -> 4096-point forward FFT (the headline) -----------------------------------------
-#ifndef YG_FUSED_WAVES
-#define YG_FUSED_WAVES 2
-#endif
-__global__ void __launch_bounds__(256, YG_FUSED_WAVES)
+__global__ void __launch_bounds__(256, 2)
 firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__restrict__ x,
                               const float *__restrict__ taps_pad, int L, int Lp, float scale,
                               const float2 *__restrict__ tw, float2 *__restrict__ spectra,
@@ -179,7 +174,7 @@ firfft_crcf_4096_slide_kernel(const float2 *__restrict__ win, const float2 *__re
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = fl[padded(256 * a + threadIdx.x)];
         __syncthreads();
-        fft4096_passes<-1, false, YG_FUSED_TWP>(v, fl, tw, spectra + f * kTile);
+        fft4096_passes<-1, false, kFusedTwp>(v, fl, tw, spectra + f * kTile);
     }
 }
 
@@ -211,22 +206,6 @@ static int raise_lds_limit(const void *fn, bool &done) {
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Diagnostic build only (-DYG_STAMPS, never the shipped library): s_memtime at the phase boundaries of every wave of the
-// MFMA FIR kernel, written to a buffer of their own (no output value depends on them): shares of a tile's time.
-#ifdef YG_STAMPS
-__device__ unsigned long long g_mfma_stamps[4096 * 4 * 8];
-#define YG_STAMP(i)                                                                                        \
-    do {                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        unsigned long long ts_;                                                                            \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if ((threadIdx.x & 63u) == 0 && blockIdx.x < 4096u)                                                \
-            g_mfma_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (i)] = ts_;                        \
-    } while (0)
-#else
-#define YG_STAMP(i) do { } while (0)
-#endif
 
 template <int NS>
 __device__ __forceinline__ void load_apack(float (&a)[NS], const float *__restrict__ apack) {
@@ -335,43 +314,27 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
         const size_t tile = blockIdx.x;     // one tile per workgroup, no grid-stride loop
         (void)ntiles;
         const size_t o0 = tile * TILE;
-        YG_STAMP(0);
-#ifndef YG_ABL_NOSTAGE
         stage_span(xs, win, x, (long long)o0 - (Lp - 1), TILE + Lp, L, x_len);
-#endif
         // the Toeplitz tap registers are requested AFTER the span (vmcnt retires in order: in front of it they would
         // hold up the span's LDS writes) and are first needed behind the barrier
         float a[NS];
         load_apack<NS>(a, apack);
-        YG_STAMP(1);
         __syncthreads();
-        YG_STAMP(2);
         f32x4 acc[NT][4];
-#ifndef YG_ABL_NOMFMA
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             fir_task_mfma<NS>(acc[t], a, reinterpret_cast<const float *>(xs), 512 * (wave + NW * t));
-#else
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{a[q], a[q + 4], xs[threadIdx.x + q].x, 0.f};
-#endif
-        YG_STAMP(3);
         if (!FUSED && direct) {                  // plain filter, 16-byte aligned output: registers -> HBM
             const long long nvalid = (long long)(n_units - o0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) store_task_direct(acc[t], out, o0, nvalid, 512 * (wave + NW * t), scale);
-            YG_STAMP(6);
             return;
         }
         __syncthreads();                         // all waves done reading the span: reuse it as output image
-        YG_STAMP(4);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             store_task_mfma(acc[t], reinterpret_cast<float *>(xs), 512 * (wave + NW * t), scale);
         __syncthreads();
-        YG_STAMP(5);
         if (FUSED) {
             const bool active = (NW == 4) || threadIdx.x < 256;
             float2 v[16];
@@ -380,19 +343,10 @@ fir_crcf_mfma_kernel(const float2 *__restrict__ win, const float2 *__restrict__ 
                 for (int q = 0; q < 16; ++q) v[q] = xs[padded(256 * q + threadIdx.x)];
             }
             __syncthreads();
-            fft4096_passes<-1, (NW > 4), YG_FUSED_TWP>(v, xs, tw, out + o0);
+            fft4096_passes<-1, (NW > 4), kFusedTwp>(v, xs, tw, out + o0);
         } else {
             const int nt = (int)((n_units - o0) < (size_t)TILE ? (n_units - o0) : (size_t)TILE);
-#ifndef YG_ABL_NOSTORE
             for (int o = threadIdx.x; o < nt; o += 64 * NW) out[o0 + o] = xs[padded(o)];
-#else
-            if (xs[padded(threadIdx.x)].x == 123.456f) out[o0 + threadIdx.x] = xs[padded(threadIdx.x)];
-#endif
-            YG_STAMP(6);
-#ifdef YG_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            YG_STAMP(7);
-#endif
             __syncthreads();
         }
     }
@@ -411,13 +365,10 @@ void pack_toeplitz_taps(const float *h, int L, int Lp, float *apack) {
         }
 }
 
-#ifndef YG_MFMA_TILE
-#define YG_MFMA_TILE 2048
-#endif
 template <int NS, bool FUSED, int NW>
 static int launch_mfma_t(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
                          const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st, cf32 *win_next) {
-    constexpr int TILE = FUSED ? kTile : YG_MFMA_TILE;
+    constexpr int TILE = FUSED ? kTile : 2048;
     static bool raised = false;
     YG_TRY(raise_lds_limit(reinterpret_cast<const void *>(fir_crcf_mfma_kernel<NS, FUSED, NW, TILE>), raised));
     const size_t ntiles = FUSED ? n_units : (n_units + TILE - 1) / TILE;
@@ -564,16 +515,13 @@ static int launch_mfma_stream(const cf32 *win, const cf32 *x, const float *apack
     return YAGI_OK;
 }
 
-#ifndef YG_MFMA_NW
-#define YG_MFMA_NW 4
-#endif
 template <bool FUSED>
 static int launch_mfma(const cf32 *win, const cf32 *x, const float *apack, int L, int Lp, float scale,
                        const cf32 *tw, cf32 *out, size_t n_units, hipStream_t st, cf32 *win_next = nullptr) {
     switch (Lp) {
-        case 64: return launch_mfma_t<20, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
-        case 128: return launch_mfma_t<36, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
-        case 256: return launch_mfma_t<68, FUSED, YG_MFMA_NW>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
+        case 64: return launch_mfma_t<20, FUSED, 4>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
+        case 128: return launch_mfma_t<36, FUSED, 4>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
+        case 256: return launch_mfma_t<68, FUSED, 4>(win, x, apack, L, Lp, scale, tw, out, n_units, st, win_next);
     }
     return fail(YAGI_ERR_INTERNAL, "mfma FIR: unsupported padded length %d", Lp);
 }
@@ -793,9 +741,3 @@ int launch_firfft_crcf_4096(const cf32 *win, const cf32 *x, const float *taps_pa
 }
 
 }  // namespace yagi
-
-#ifdef YG_STAMPS
-extern "C" int yagi_hip_debug_mfma_stamps(unsigned long long *dst, size_t count) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(yagi::g_mfma_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#endif
