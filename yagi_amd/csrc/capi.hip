@@ -2379,7 +2379,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         YG_TRY(f.prepare_conv());
         if (!f.hfreq_s_valid || f.hfreq_s_scale != f.scale) {
             YG_TRY(f.hfreq_s.ensure(4096 * sizeof(cf32)));
-            YG_TRY(launch_scale_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), 4096, f.st));
+            YG_TRY(launch_scale_pairs_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), f.st));
             YG_TRY(f.gfft_s.ensure(512 * sizeof(cf32)));
             YG_TRY(launch_scale_cf32(f.gfft.as<cf32>(), f.scale, f.gfft_s.as<cf32>(), 512, f.st));
             f.hfreq_s_valid = true;
