@@ -195,7 +195,7 @@ def main():
                          "gloo lets several ranks share one GPU when rehearsing the N>1 path on a 1-GPU box)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="headline through plain block calls on one stream instead of the pipelined calls "
-                         "(yagi_hip_firfft_crcf_set_pipeline: consecutive blocks overlap on three streams of the object)")
+                         "(yagi_hip_firfft_crcf_set_pipeline: consecutive blocks overlap on two streams of the object)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -589,7 +589,7 @@ def main():
                        "samples_per_step_per_gpu": ntot, "blocks_per_step": nb, "samples_per_block": n,
                        "frames_per_block": nframes, "nfft": NFFT, "taps": TAPS,
                        "parallelism": f"{world} independent stream(s), no collective",
-                       "block_calls": "pipelined (set_pipeline: consecutive execute_dev calls rotate over three "
+                       "block_calls": "pipelined (set_pipeline: consecutive execute_dev calls alternate between two "
                                       "streams of the object, joined into the launch stream once per step)"
                                       if pipelined else "plain (one stream)",
                        "kernel": kernel_name, "variant": args.variant, "prewarm_ms": args.prewarm_ms},

@@ -499,7 +499,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x_
                                      size_t nframes, yagi_cf32 *spectra_dev);
 /* Pipelined block calls (frequency-domain form, nfft = 4096).  Consecutive blocks of the stream depend on each other
  * only through the L-sample filter window (firfilt.rs:13,220-223), and that window is the previous block's own last L
- * INPUT samples.  With the pipeline on, execute_dev runs consecutive blocks in rotation on three streams owned by the
+ * INPUT samples.  With the pipeline on, execute_dev runs consecutive blocks alternately on two streams owned by the
  * object, block b + 1 reading its window straight from the tail of block b's x_dev, so block b + 1 ramps up while
  * block b drains.  The contract changes in one point: x_dev must be complete on the object's stream when execute_dev
  * is called (as before), but spectra_dev -- and the right to overwrite or free x_dev -- is ordered on the object's

@@ -703,7 +703,7 @@ def test_per_sample_firpfb_and_firdecim_on_the_host_mirror(ya, oracle, kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 def test_firfilt_pipelined_blocks_bit_identical(ya, kind):
-    """set_pipeline(1) on FirFilter: consecutive execute_block_dev calls run on three streams of the object, each reading its
+    """set_pipeline(1) on FirFilter: consecutive execute_block_dev calls run on two streams of the object, each reading its
     window from the tail of the previous call's input; after join() every output is bit for bit the unpipelined one --
     every kernel choice, ragged blocks (shorter than the filter: those calls join and run unpipelined), per-sample and
     host-pointer calls and a reset in between"""

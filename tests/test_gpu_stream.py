@@ -178,7 +178,7 @@ def test_stream_pure_delay_whole_block(ya, delay):
 
 
 def test_stream_pipelined_blocks_bit_identical(ya, oracle):
-    """set_pipeline(1): consecutive execute_dev calls run on three streams of the object, each block reading its window
+    """set_pipeline(1): consecutive execute_dev calls run on two streams of the object, each block reading its window
     from the previous call's input; after join() the spectra are bit for bit those of the unpipelined calls -- every block seam, ragged
     block lengths, a scale change, reset, and a host-pointer call in between"""
     h = oracle.fir_design_kaiser(256, 0.2, 60.0)

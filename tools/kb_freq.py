@@ -34,7 +34,7 @@ def make(form):
     q.set_scale(0.4)
     q.set_variant(form % 100)
     q.set_stream(st.cuda_stream)
-    if form >= 100:                 # 104 = variant 4 with pipelined block calls (three streams of the object)
+    if form >= 100:                 # 104 = variant 4 with pipelined block calls (two streams of the object)
         q.set_pipeline(True)
     return q
 

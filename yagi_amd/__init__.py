@@ -316,7 +316,7 @@ class FirFilter(_FirBase):
         _check(self._fn("execute_block_dev")(self._h, _devptr(x_dev), n, _devptr(y_dev)))
 
     def set_pipeline(self, on=True):
-        """pipelined block calls (include/yagi_hip.h): consecutive execute_block_dev calls overlap on three streams of the
+        """pipelined block calls (include/yagi_hip.h): consecutive execute_block_dev calls overlap on two streams of the
         object; outputs (and the right to overwrite the inputs) are ordered on the object's stream after join()"""
         _check(self._fn("set_pipeline")(self._h, 1 if on else 0))
 
@@ -981,7 +981,7 @@ class FirFftStream(_Handle):
         _check(lib.yagi_hip_firfft_crcf_execute_dev(self._h, _devptr(x_dev), nframes, _devptr(spectra_dev)))
 
     def set_pipeline(self, on=True):
-        """pipelined block calls: consecutive execute_dev calls overlap on three streams owned by the object;
+        """pipelined block calls: consecutive execute_dev calls overlap on two streams owned by the object;
         their outputs are ordered on the object's stream only after join() (include/yagi_hip.h)"""
         _check(lib.yagi_hip_firfft_crcf_set_pipeline(self._h, 1 if on else 0))
 

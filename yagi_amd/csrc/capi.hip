@@ -57,17 +57,17 @@ static int download(void *dst, const void *src, size_t bytes, hipStream_t st) {
 // Pipelined block calls (yagi_hip_firfft_crcf_set_pipeline, yagi_hip_firfilt_*_set_pipeline).  Consecutive blocks of the stream depend on each other
 // only through the L-sample filter window, and that window is INPUT data (the previous block's last L samples), which
 // the pipelined contract keeps intact until the join: block b + 1 reads it straight from the previous call's x, so it
-// needs nothing block b computes.  The block kernels rotate over three streams (lanes) owned by the handle; call b does
-//     caller's stream: record `in`           lane b % 3: wait(in), block kernel b, record done[b % 3]
+// needs nothing block b computes.  The block kernels alternate between two streams (lanes); call b does
+//     caller's stream: record `in`           lane b % 2: wait(in), block kernel b, record done[b % 2]
 // so block b + 1 ramps up while block b drains (on one stream every kernel waits for the complete drain of the one
 // before it: ~4 us of a 61 us block).  The caller's stream is NOT made to wait per call (its next `in` would inherit
 // that wait and serialise the blocks); it joins the lanes in *_join (DevWindow::join), which every other use of the
 // object's window goes through first and which also copies the last block's tail into the object's window.
 struct StreamPipe {
     bool on = false;
-    // three lanes: 55.5 us per block of the headline stream against 56.2 with two and 60.6 with four (the device exposes
-    // four hardware queues and the caller's stream is one of them): tools/ab_libs.py, profiles/r03_notes.md
-    static constexpr int kLanes = 3;
+    // two lanes (a device exposes four hardware queues, the caller's stream and the null stream take two): in the bench
+    // three lanes read the same, four lose 8 %
+    static constexpr int kLanes = 2;
     hipStream_t lane[kLanes] = {};
     hipEvent_t in = nullptr, done[kLanes] = {};
     bool busy[kLanes] = {};
@@ -2365,7 +2365,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         return f.w.advance(x, n, f.st);
     }
     if (piped) {
-        // the frequency-domain kernel on lane b % 3 (see StreamPipe); tables and scaled FFT{h} are in place
+        // the frequency-domain kernel on the next lane (see StreamPipe); tables and scaled FFT{h} are in place
         const size_t n = nframes * q->nfft;
         hipStream_t lane;
         const cf32 *win;
@@ -2379,7 +2379,7 @@ int yagi_hip_firfft_crcf_execute_dev(yagi_hip_firfft_crcf q, const yagi_cf32 *x,
         YG_TRY(f.prepare_conv());
         if (!f.hfreq_s_valid || f.hfreq_s_scale != f.scale) {
             YG_TRY(f.hfreq_s.ensure(4096 * sizeof(cf32)));
-            YG_TRY(launch_scale_pairs_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), f.st));
+            YG_TRY(launch_scale_cf32(f.hfreq.as<cf32>(), f.scale, f.hfreq_s.as<cf32>(), 4096, f.st));
             YG_TRY(f.gfft_s.ensure(512 * sizeof(cf32)));
             YG_TRY(launch_scale_cf32(f.gfft.as<cf32>(), f.scale, f.gfft_s.as<cf32>(), 512, f.st));
             f.hfreq_s_valid = true;

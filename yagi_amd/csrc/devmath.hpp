@@ -148,7 +148,6 @@ __device__ __forceinline__ void batched_for(int total, Load load, Store store) {
 // flat form spends ~3 VALU + a carry-hazard nop on every 64-bit address); an access at or beyond `bytes` reads zero /
 // is dropped, which makes the tail checks of a partial tile free
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }

@@ -39,10 +39,6 @@ namespace yagi {
 // once and the spectra are written once, so the frame loads bypass the CU's L1 (sc1: the tables the four resident
 // workgroups share stay there) and the stores are non-temporal (nt): interleaved A/B on the streamed workload,
 // tools/ab_libs.py: stores nt -4.6 ... -6.7 %, loads sc1 a further -2.3 %; nt LOADS +10 %, sc0 on either +13 ... +18 %.
-// The CU's 32 KiB L1 belongs to ONE table: FFT{h} (32 KiB, re-read by every frame: an ablation without its loads runs
-// 16.6 % faster).  Every other table access -- twiddle rows, wave 0's correction operands and twiddles, the frame tails --
-// also bypasses L1 (ld_stream = sc1), so nothing evicts it: -7.7 %.  FFT{h} itself is stored pair-interleaved and read
-// with eight 16-byte loads per lane instead of sixteen 8-byte ones (-1.2 ... -1.5 %).
 //
 // WHAT BOUNDS IT (profiles/r03_notes.md).  The chip's power envelope: tools/kb_power.py reads 1383 W (cap 1400 W) and a
 // shader clock throttled to 2.05 GHz while this kernel streams random data, 1225 W at 2.39 GHz on all-zero input --
@@ -217,14 +213,14 @@ __device__ __forceinline__ void freq_load_corr_fft(CorrOperands &o, const float2
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const unsigned m = 64u * a + l, mi = (int)m < Lc ? m : 0u;
-        o.dp[a] = ld_stream(prev + mi);
-        o.dq[a] = ld_stream(own + mi);
+        o.dp[a] = prev[mi];
+        o.dq[a] = own[mi];
     }
-    o.w1 = ld_stream(tw + 8u * l); o.w2 = ld_stream(tw + 16u * l); o.w4 = ld_stream(tw + 32u * l);
+    o.w1 = tw[8u * l]; o.w2 = tw[16u * l]; o.w4 = tw[32u * l];
     const unsigned bp = l & 7u;
-    o.u1 = ld_stream(tw + 64u * bp); o.u2 = ld_stream(tw + 128u * bp); o.u4 = ld_stream(tw + 256u * bp);
+    o.u1 = tw[64u * bp]; o.u2 = tw[128u * bp]; o.u4 = tw[256u * bp];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) o.gc[d] = ld_stream(gfft + l + 64u * d);
+    for (int d = 0; d < 8; ++d) o.gc[d] = gfft[l + 64u * d];
 }
 // c_f[0 .. 256) -> cvs, by wave 0 (l = threadIdx.x < 64); scr = 1120 float2 of LDS nobody else touches meanwhile
 __device__ __forceinline__ void freq_correction_fft(const CorrOperands &o, int L, float2 *__restrict__ scr,
@@ -260,7 +256,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     const unsigned t = threadIdx.x, f = blockIdx.x;
     const bool wave0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
     // ---- head: every load the frame needs, wave 0's correction operands first ----
-    const float2 tw_t = ld_stream(ax + 1280 + t);
+    const float2 tw_t = ax[1280 + t];
     float2 v[16];
     CorrOperands co;
     if (wave0) freq_load_corr_fft(co, win, x, L, f, tw, gfft);
@@ -282,7 +278,7 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     dft16<-1>(v);
     {
         float2 w[16];
-        twiddle_powers_from(w, ld_stream(ax + t), ld_stream(ax + 256 + t), ld_stream(ax + 512 + t), ld_stream(ax + 768 + t));
+        twiddle_powers_from(w, ax[t], ax[256 + t], ax[512 + t], ax[768 + t]);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float2 z = v[dft16_pos(c)];
@@ -293,24 +289,16 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
     __syncthreads();
     freq_pass23(v, lds, T);
     {
-        // the table is stored pair-interleaved, hs2[j][t] = {FFT{h}[t + 256 (2j)], FFT{h}[t + 256 (2j + 1)]}: eight 16-byte
-        // loads per lane instead of sixteen 8-byte ones (-1.5 %).  An ablation without these loads runs 16.6 % faster: the
-        // table's trip through the address / L1 path is the kernel's largest single cost after the frame itself; issuing
-        // the loads a pass ahead does not change that (+0.6 %)
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(hs, 32768u);
         float2 hv[16];
 #pragma unroll
-        for (unsigned j = 0; j < 8; ++j) {
-            const v4u_t q = __builtin_amdgcn_raw_buffer_load_b128(rh, 16u * t, 4096u * j, 0);      // a table: cached
-            hv[2 * j] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-            hv[2 * j + 1] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
-        }
+        for (unsigned d = 0; d < 16; ++d) hv[d] = buf_ld_aux<0>(rh, 8u * t, 2048u * d);      // a table: cached
 #pragma unroll
         for (unsigned d = 0; d < 16; ++d) v[d] = cmul(v[d], hv[d]);
     }
     // ---- correction transform, sum, store ----
     float2 u[16];
-    freq_head256(cvs, u, lds, T, ld_stream(ax + 1024 + t));
+    freq_head256(cvs, u, lds, T, ax[1024 + t]);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)f * 4096, 32768u);
 #pragma unroll
     for (unsigned d = 0; d < 16; ++d)
@@ -320,17 +308,6 @@ firfft_crcf_4096_freq_kernel(const float2 *__restrict__ win, const float2 *__res
 __global__ void scale_cf32_kernel(const float2 *__restrict__ src, float s, float2 *__restrict__ dst, unsigned n) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = make_float2(src[i].x * s, src[i].y * s);
-}
-__global__ void scale_pairs_cf32_kernel(const float2 *__restrict__ src, float s, float2 *__restrict__ dst) {
-    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;            // k = t + 256 d < 4096
-    const unsigned t = k & 255u, d = k >> 8;
-    dst[512u * (d >> 1) + 2u * t + (d & 1u)] = make_float2(src[k].x * s, src[k].y * s);
-}
-// the headline kernel's FFT{h} table: scaled and pair-interleaved (see the kernel)
-int launch_scale_pairs_cf32(const cf32 *src, float s, cf32 *dst, hipStream_t st) {
-    scale_pairs_cf32_kernel<<<16, 256, 0, st>>>(reinterpret_cast<const float2 *>(src), s, reinterpret_cast<float2 *>(dst));
-    YG_LAUNCH_CHECK();
-    return YAGI_OK;
 }
 // dst[i] = s * src[i] (the scaled copy of FFT{h} the stream kernel multiplies by)
 int launch_scale_cf32(const cf32 *src, float s, cf32 *dst, size_t n, hipStream_t st) {

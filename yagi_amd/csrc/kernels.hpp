@@ -110,7 +110,6 @@ int launch_firfft_crcf_4096_freq(const cf32 *win, const cf32 *x, const cf32 *hs_
                                  hipStream_t st);
 
 int launch_scale_cf32(const cf32 *src, float s, cf32 *dst, size_t n, hipStream_t st);
-int launch_scale_pairs_cf32(const cf32 *src, float s, cf32 *dst, hipStream_t st);
 
 // ---- resamp2_kernels.hip -------------------------------------------------------------------
 // forms of Resamp2 (resamp2.rs:104-180); values are the `mode` argument of the C ABI
