@@ -239,8 +239,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(fn, reps, stream):
-        """mean device ms of fn() over reps calls (HIP events on the launch stream)"""
+    def timed(fn, reps, stream, warm_ms=80.0):
+        """mean device ms of fn() over reps calls (HIP events on the launch stream).  Every leg first keeps the device busy
+        with its own kernel for warm_ms: the legs follow host-side work (object set-up, PCIe copies, the parity check) and a
+        GPU that has idled for a few ms runs its next ~50 launches up to 25 % slower"""
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < warm_ms:
+            fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):

@@ -8,6 +8,6 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 for i in $(seq 1 $rounds); do
   for lib in "$@"; do
     if [ "$lib" != "-" ]; then export YAGI_HIP_LIB=$root/yagi_amd/variants/libyagi_$lib.so; else unset YAGI_HIP_LIB; fi
-    python3 $root/bench.py --no-extras --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib=$lib', o['value'], o['roofline']['frac'], o['roofline']['kernel_ms'])"
+    python3 $root/bench.py --no-extras --no-cpu-baseline $AB_BENCH_ARGS 2>/dev/null | python3 -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib=$lib', o['value'], o['roofline']['frac'], o['roofline']['kernel_ms'])"
   done
 done
