@@ -267,15 +267,26 @@ __host__ __device__ inline int frfast_pitch(int N, int nfr) { return N + 32 / nf
 // workgroup owns 16/M transforms; transform tr = t / 16M, lane u = t % 16M within it.
 //   in : v[a] = x[16M a + u], a < 16
 //   out: v[i M + d] = X[u + 16M i + 256 d],  i < 16/M, d < M
-// `lds` = kFft4096LdsFloat2 float2; 3 __syncthreads(), every lane must call it (the caller adds one before
-// reusing `lds`).  Exchange strides 17M and 256 + 16/M keep all LDS accesses bank-conflict free.
+// `lds` = kFft4096LdsFloat2 float2.  Exchange strides 17M and 256 + 16/M keep all LDS accesses bank-conflict free.
+// M <= 4: a transform's 16M lanes are one wave (or a part of one) and both exchanges stay inside the transform's own
+// 272M-float2 slot, so the exchanges order themselves with wave barriers (the LDS serves a wave's accesses in issue
+// order) and the function holds no __syncthreads(); at M = 1 the second exchange would hand every lane its own values
+// back (pass 2 already leaves X[u + 16 c'] in lane u) and is a register renaming instead.  M = 8: a transform spans two
+// waves, 3 __syncthreads().  Every lane must call it; the caller puts a __syncthreads() between this function and its
+// own use of `lds` either side.
 template <int SIGN, int M>
 __device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2 *__restrict__ lds,
                                                          const float2 *__restrict__ tw) {
     constexpr int N = 256 * M, LT = 16 * M, B = 16 / M;
     constexpr int S1 = 17 * M, T1 = 16 * S1;                    // exchange 1: row stride, transform stride
     constexpr int S2 = 256 + 16 / M, T2 = M * S2;               // exchange 2
-    static_assert(B * T1 <= kFft4096LdsFloat2 && B * T2 <= kFft4096LdsFloat2, "LDS layout");
+    constexpr bool kInWave = LT <= 64;
+    constexpr int T2s = kInWave ? T1 : T2;                      // in-wave: exchange 2 in the transform's exchange-1 slot
+    static_assert(T2 <= T1 && B * T1 <= kFft4096LdsFloat2 && B * T2 <= kFft4096LdsFloat2, "LDS layout");
+    auto sync = [] {
+        if constexpr (kInWave) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     const unsigned t = threadIdx.x, tr = t / LT, u = t % LT;
     // ---- pass 1 ----
     dft16<SIGN>(v);
@@ -290,20 +301,24 @@ __device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2
             e1[c * S1] = z;
         }
     }
-    __syncthreads();
+    sync();
     // ---- pass 2 ----
     {
         const unsigned c = u / M, bp = u % M;
         const float2 *e1 = lds + tr * T1 + c * S1 + bp;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = e1[M * a];
-        __syncthreads();                                         // exchange-1 reads done before the buffer is reused
+        sync();                                                  // exchange-1 reads done before the buffer is reused
         dft16<SIGN>(v);
-        float2 *e2 = lds + tr * T2 + bp * S2 + c;
-        if constexpr (M == 1) {                                  // b' = 0: every twiddle of this pass is 1
+        if constexpr (M == 1) {                                  // b' = 0: every twiddle of this pass is 1, and lane u = c
+            float2 r[16];                                        // already holds X[u + 16 c']
 #pragma unroll
-            for (int cp = 0; cp < 16; ++cp) e2[16 * cp] = v[dft16_pos(cp)];
+            for (int cp = 0; cp < 16; ++cp) r[cp] = v[dft16_pos(cp)];
+#pragma unroll
+            for (int cp = 0; cp < 16; ++cp) v[cp] = r[cp];
+            return;
         } else {
+            float2 *e2 = lds + tr * T2s + bp * S2 + c;
             float2 w[16];
             twiddle_powers(w, tw, 16 * bp, (unsigned)(N - 1));  // W_{16M}^{b' c'} = W_N^{16 b' c'}
 #pragma unroll
@@ -314,10 +329,10 @@ __device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2
             }
         }
     }
-    __syncthreads();
+    sync();
     // ---- pass 3: 16/M radix-M butterflies per lane ----
     {
-        const float2 *e2 = lds + tr * T2 + u;
+        const float2 *e2 = lds + tr * T2s + u;
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             float2 r[M];
@@ -328,6 +343,7 @@ __device__ __forceinline__ void fft_n256m_passes_to_regs(float2 (&v)[16], float2
             for (int d = 0; d < M; ++d) v[i * M + d] = r[dftR_pos<M>(d)];
         }
     }
+    sync();                                                      // in-wave: the caller's next writes stay behind these reads
 }
 
 }  // namespace yagi
