@@ -177,11 +177,13 @@ def test_msresamp2_vs_oracle(ya, oracle, kind, interp):
         assert got.shape == want.shape and rel_l2(got, want) <= 3e-6, (kind, interp, ns)
 
 
-@pytest.mark.parametrize("kind,ms", [("crcf", [10, 5, 3]), ("rrrf", [6, 4]), ("cccf", [4, 3, 3, 2])])
+@pytest.mark.parametrize("kind,ms", [("crcf", [10, 5, 3]), ("rrrf", [6, 4]), ("cccf", [4, 3, 3, 2]), ("crcf", [7]),
+                                     ("cccf", [2, 13, 6]), ("rrrf", [12, 2, 9]), ("crcf", [2, 2, 2]), ("rrrf", [30, 17])])
 def test_msresamp2_fused_decimator_equals_the_chain_on_a_large_block(ya, oracle, kind, ms):
     """the decimator chain in one launch (<= 4 stages, LDS-resident intermediates, several tiles per workgroup from
-    8192 tiles on) against the same stages run one after the other as Resamp2 objects: identical bits, over two calls
-    (the windows of every stage written by the fused kernel's last workgroup carry into the second call)"""
+    8192 tiles on; up to three stages: the middle of the block through msresamp2_decim_fast_kernel, its two ends through
+    the general kernel) against the same stages run one after the other as Resamp2 objects: identical bits, over two
+    calls (the windows of every stage written by the fused kernel's last workgroup carry into the second call)"""
     ns = len(ms)
     rate = 1 << ns
     hfs = [oracle.halfband_kaiser(m, 60.0) for m in ms]

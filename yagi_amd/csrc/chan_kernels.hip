@@ -872,11 +872,14 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
     constexpr int pitch = col_pitch(M, nq);
     const int Mr = SHARDED ? M / R : M;
     const int lgMr = 31 - __builtin_clz((unsigned)Mr);
-    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][pitch]
+    constexpr bool kRegTile = !SHARDED && LGM == 8;             // see the end of the kernel
+    constexpr int kRegPitch = 272;                              // = 16 mod 32: two transforms of a half wave on disjoint banks
+    float2 *va = reinterpret_cast<float2 *>(smem);              // [256/M groups][8 steps][pitch]; kRegTile: [16 steps][272]
     float2 *vb = va + nq * pitch;
     float2 *twl = vb + nq * pitch;                              // M
     const int g = threadIdx.x >> lgM, b = threadIdx.x & (M - 1);
-    for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
+    if constexpr (!kRegTile)
+        for (int e = threadIdx.x; e < M; e += 256) twl[e] = twM[e];
     const int bpar = (b >= M2) ? 1 : 0;
     const int pos = bpar ? (M - 1 - b) : (M2 - 1 - b);
     const int i1 = (b - M2 + M) & (M - 1);
@@ -996,6 +999,74 @@ firpfbch2_col_kernel(const float2 *__restrict__ hist, int hist_len, const float2
         }
         __syncthreads();
     };
+    if constexpr (kRegTile) {
+        // M = 256: 16 steps per tile, their 256-point transforms in registers (the scheme of fft_n256m_passes_to_regs,
+        // M = 1): lane (tr, u) = (t / 16, t % 16) takes V[step tr][16 a + u] out of the tile, and the exchange between
+        // the two radix-16 passes stays inside the transform's 16 lanes -- a quarter of a wave, ordered by wave
+        // barriers.  Every lane is busy in both passes (the LDS Stockham form kept 128 of 256), three workgroup
+        // barriers per 16 steps instead of six, and the bins leave from registers as 128-byte runs.
+        const unsigned tr = threadIdx.x >> 4, u = threadIdx.x & 15u;
+        float2 wq[16];                                                   // W_256^{-u c}: constant over the launch
+#pragma unroll
+        for (int c = 1; c < 16; ++c) {
+            const float2 e = twM[(u * (unsigned)c) & 255u];
+            wq[c] = make_float2(e.x, -e.y);
+        }
+        constexpr int kTilePairs = kColTile / 2;
+        float2 xin[kTilePairs];
+        auto load8 = [&](int t) {
+#pragma unroll
+            for (int kk = 0; kk < kTilePairs; ++kk) {
+                if constexpr (FULL) xin[kk] = buf_ld_aux<kAnaLoad>(rx, vx, 8u * ((unsigned)(t / 2 + kk) << lgM));
+                else xin[kk] = (t + 2 * kk + bpar < nvalid) ? xg[(unsigned)(t / 2 + kk) << lgM] : make_float2(0.f, 0.f);
+            }
+        };
+        load8(0);
+        for (int t = 0; t < run; t += kColTile) {
+#pragma unroll
+            for (int kk = 0; kk < kTilePairs; ++kk) {                    // the same chains as half_tile's
+                typedef float v4f_t __attribute__((ext_vector_type(4)));
+                const float2 old = w[kk % P];
+                const float2 new0 = bpar ? old : xin[kk];
+                w[kk % P] = xin[kk];
+                v4f_t a01 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const float2 s1 = w[(kk - m + 4 * P) % P];
+                    const float2 s0 = m == 0 ? new0 : s1;
+                    a01 = __builtin_elementwise_fma(v4f_t{s0.x, s0.y, s1.x, s1.y}, v4f_t{h0r[m], h0r[m], h1[m], h1[m]}, a01);
+                }
+                va[(2 * kk) * kRegPitch + b] = make_float2(a01.x, a01.y);
+                va[(2 * kk + 1) * kRegPitch + b] = make_float2(a01.z, a01.w);
+            }
+            if (t + kColTile < run) load8(t + kColTile);                 // in flight during the transforms
+            __syncthreads();
+            float2 v[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = va[tr * kRegPitch + 16 * a + u];
+            __syncthreads();                                             // the tile is out before its slots turn into exchanges
+            dft16<+1>(v);
+            float2 *ex = va + tr * kRegPitch;                            // [c][b], row stride 17
+            ex[u] = v[dft16_pos(0)];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) ex[c * 17 + u] = cmul(v[dft16_pos(c)], wq[c]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = ex[u * 17 + a];
+            dft16<+1>(v);                                                // lane u: bins u + 16 c'
+#pragma unroll
+            for (int cp = 0; cp < 16; ++cp) {
+                const float2 o = v[dft16_pos(cp)];
+                if constexpr (FULL)
+                    buf_st_aux<kAnaStore>(ry, 8u * ((tr << lgM) + u + 16u * cp), 8u * ((unsigned)t << lgM),
+                                          make_float2(o.x * invM, o.y * invM));
+                else if (t + (int)tr < nvalid)
+                    yb[(size_t)(t + tr) * M + u + 16 * cp] = make_float2(o.x * invM, o.y * invM);
+            }
+            __syncthreads();                                             // exchanges read before the next tile lands
+        }
+        return;
+    }
     load4(xa, 0);
     load4(xb, kColHalf);
     for (int t0 = 0; t0 < run; t0 += kColTile) {
@@ -1017,7 +1088,9 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
     const size_t ngroups = (nsteps + run - 1) / run;
     const size_t nblk = (ngroups + G - 1) / G;
     if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
-    const size_t lds = (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
+    const size_t lds = (LGM == 8 && nranks <= 1)
+                           ? (size_t)kColTile * 272 * sizeof(float2)       // the register-transform tile (kRegTile)
+                           : (2 * (size_t)G * kColHalf * col_pitch(M, G * kColHalf) + (size_t)M) * sizeof(float2);
     const float2 *fh = reinterpret_cast<const float2 *>(hist), *fx = reinterpret_cast<const float2 *>(x);
     const float2 *ftw = reinterpret_cast<const float2 *>(twM);
     float2 *fy = reinterpret_cast<float2 *>(y), *fn = reinterpret_cast<float2 *>(hist_next);

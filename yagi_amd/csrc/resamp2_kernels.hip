@@ -193,18 +193,25 @@ struct MsDecimArgs {
 
 template <class T, class C, int S>
 __global__ void __launch_bounds__(256)
-msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restrict__ y, size_t nout, int tpw) {
+msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restrict__ y, size_t nout, int tpw,
+                       long long head_tiles, long long tail_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_lds[];   // S is a template parameter: every per-stage array below lives in registers
     constexpr int NP = (1 << (S - 1)) + 1;                       // input pairs per lane and tile: (256 * 2^(S-1) + halo) / 256
-    const long long ntiles = ((long long)nout + kMsTile - 1) / kMsTile;
+    // the launch covers the outputs [0, 256 head_tiles) and [tail_first, nout): everything when tail_first = 256 head_tiles,
+    // the two ends of the block when msresamp2_decim_fast_kernel takes the tiles in between
+    const long long ntiles = head_tiles + (((long long)nout - tail_first) + kMsTile - 1) / kMsTile;
     const long long npairs = (long long)nout << (S - 1);         // pairs of the block's input
     const long long tile0 = (long long)blockIdx.x * tpw;
     const long long tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+    auto first_output = [&](long long tile) {
+        return tile < head_tiles ? tile * kMsTile : tail_first + (tile - head_tiles) * kMsTile;
+    };
     // output ranges of the stages of a tile, last to first (pair indices; may start below zero near the block's start)
     long long ua[kMsMaxStages], ub[kMsMaxStages];
     auto ranges = [&](long long tile) {
-        const long long o0 = tile * kMsTile;
-        long long lo = o0, hi = o0 + kMsTile < (long long)nout ? o0 + kMsTile : (long long)nout;
+        const long long o0 = first_output(tile);
+        const long long oend = tile < head_tiles && head_tiles * kMsTile < (long long)nout ? head_tiles * kMsTile : (long long)nout;
+        long long lo = o0, hi = o0 + kMsTile < oend ? o0 + kMsTile : oend;
 #pragma unroll
         for (int k = S - 1; k >= 0; --k) {
             ua[k] = lo;
@@ -218,7 +225,7 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
     T qe[NP], qo[NP];
     const int m20 = 2 * a.m[0];
     auto issue = [&](long long tile) {                           // clamped: entries below zero are replaced at commit
-        long long lo = tile * kMsTile;
+        long long lo = first_output(tile);
 #pragma unroll
         for (int k = S - 1; k >= 1; --k) lo = 2 * (lo - (2 * a.m[k] - 1));
         const long long u0 = lo - (m20 - 1);                        // pair index of the tile's stream entry 0
@@ -326,6 +333,165 @@ msresamp2_decim_kernel(MsDecimArgs<T, C> a, const T *__restrict__ x, T *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same chain for the tiles in the middle of a block (S <= 3): every index of such a tile lies inside the block's
+// input, its geometry is the same for all of them, and so nothing of it is computed per tile or per lane -- the general
+// kernel above spends ~800 instructions per wave and tile (index arithmetic, range checks, one LDS read per tap and
+// output) around ~100 of arithmetic and is bound by instruction issue (178 us of 228 with the loads removed, r03_notes.md).
+// Here stage k gives every lane R_k = 2^(S-1-k) CONSECUTIVE outputs (4 / 2 / 1 at three stages: all stages keep the
+// workgroup's lanes busy, which four-per-lane everywhere did not), the stream entries a lane needs are walked once with
+// R_k accumulators (one LDS read per R_k taps' worth of FMAs), and the streams lie in R_k planes -- entry e at plane
+// e mod R_k, position e div R_k -- so that for every step of the walk the lanes read consecutive positions of one plane,
+// and a lane's R_k outputs land at position `lane` of the next stage's planes: no bank conflicts, no per-lane offsets.
+// A tile makes F final outputs, F the largest count whose stage-0 streams fit 256 R_0 pairs (231 for m = 3 / 5 / 10).
+// Each output is the same FMA chain in tap order as in resamp2_kernel: bit-identical to the chain of launches.
+// ---------------------------------------------------------------------------------------------
+struct MsFastGeom {
+    int F;                      // final outputs per tile
+    int n[3];                   // outputs of stage k per tile
+    int cnt0;                   // input pairs per tile
+    int U;                      // first input pair of a tile = 2^(S-1) * (its first output) - U
+};
+
+template <class T> struct MsPair { T e, o; };
+
+// R consecutive outputs of one stage for the lane whose first entry is at S1l / S0l (plane 0, the lane's position)
+template <class T, class C, int R>
+__device__ __forceinline__ void ms_fast_stage(const T *__restrict__ S1l, const T *__restrict__ S0l, int PS,
+                                              const C *__restrict__ h, int m, C scale, T (&out)[R]) {
+    constexpr int lgR = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const int m2 = 2 * m;
+    T acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = zero_of<T>();
+    if constexpr (R == 1) {
+        acc[0] = r2_branch<T, C>(S1l, h, m2);
+    } else {
+        // entry t = R g + c feeds output r with tap t - r; per output the taps arrive in rising order
+        const int G = (m2 + 2 * R - 2) / R;
+        for (int g = 0; g < G; ++g) {
+            T wv[R];
+#pragma unroll
+            for (int c = 0; c < R; ++c) wv[c] = S1l[c * PS + g];
+            const int t0 = R * g;
+            if (t0 >= R - 1 && t0 + R - 1 < m2) {                    // every (entry, output) pair of the group is a tap
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] = mac(acc[r], wv[c], h[t0 + c - r]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < R; ++c)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int kk = t0 + c - r;                   // wave-uniform
+                        if (kk >= 0 && kk < m2) acc[r] = mac(acc[r], wv[c], h[kk]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int tt = r + m - 1;                                    // the delay branch: entry (first entry) + r + m - 1
+        out[r] = mul(add(S0l[(tt & (R - 1)) * PS + (tt >> lgR)], acc[r]), scale);
+    }
+}
+
+template <class T> __host__ __device__ constexpr int ms_plane_stride(int R) {
+    // >= 256 positions; the stage-0 fill (lane -> plane lane mod R, position lane div R) spreads over the banks
+    return 256 + (R > 1 ? (sizeof(T) == 4 ? 64 : 32) / R : 0);
+}
+
+template <class T, class C, int S>
+__global__ void __launch_bounds__(256)
+msresamp2_decim_fast_kernel(MsDecimArgs<T, C> a, MsFastGeom geo, const T *__restrict__ x, T *__restrict__ y,
+                            long long o_first, int ntiles, int tpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ms_lds[];
+    static_assert(S >= 1 && S <= 3, "R_0 <= 4");
+    constexpr int R0 = 1 << (S - 1), lgR0 = S - 1;
+    const int tid = threadIdx.x;
+    // streams: per stage S1 (filter branch), then S0 (delay branch), R_k planes each
+    T *S1p[S], *S0p[S];
+    {
+        T *p = reinterpret_cast<T *>(ms_lds);
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int R = 1 << (S - 1 - k), PS = ms_plane_stride<T>(R);
+            S1p[k] = p;
+            S0p[k] = p + R * PS;
+            p += 2 * R * PS;
+        }
+    }
+    const int tile0 = blockIdx.x * tpw;
+    const int tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+    MsPair<T> q[R0];
+    auto issue = [&](int tile) {
+        const long long u0 = ((o_first + (long long)tile * geo.F) << (S - 1)) - geo.U;       // >= 0: the launcher's choice
+        const MsPair<T> *xb = reinterpret_cast<const MsPair<T> *>(x) + u0;
+#pragma unroll
+        for (int b = 0; b < R0; ++b)
+            if (tid + 256 * b < geo.cnt0) q[b] = xb[tid + 256 * b];
+    };
+    if (tile0 < tend) issue(tile0);
+    for (int tile = tile0; tile < tend; ++tile) {
+        {   // stage 0's streams: pair j = tid + 256 b -> plane j mod R0, position j div R0
+            constexpr int PS = ms_plane_stride<T>(R0);
+            T *d1 = S1p[0] + (tid & (R0 - 1)) * PS + (tid >> lgR0), *d0 = S0p[0] + (tid & (R0 - 1)) * PS + (tid >> lgR0);
+#pragma unroll
+            for (int b = 0; b < R0; ++b) {
+                d1[(256 / R0) * b] = q[b].e;
+                d0[(256 / R0) * b] = q[b].o;
+            }
+        }
+        if (tile + 1 < tend) issue(tile + 1);
+        auto lanes = [&](int k) { return (geo.n[k] + (1 << (S - 1 - k)) - 1) >> (S - 1 - k); };   // lanes with an output
+        if constexpr (S == 3) {
+            __syncthreads();
+            if (tid < lanes(0)) {
+                T out[4];
+                ms_fast_stage<T, C, 4>(S1p[0] + tid, S0p[0] + tid, ms_plane_stride<T>(4), a.h1[0], a.m[0], a.scale[0], out);
+                constexpr int PSn = ms_plane_stride<T>(2);           // outputs 4 tid + r = the next stage's pairs 2 tid, 2 tid + 1
+                S1p[1][tid] = out[0];
+                S0p[1][tid] = out[1];
+                S1p[1][PSn + tid] = out[2];
+                S0p[1][PSn + tid] = out[3];
+            }
+        }
+        if constexpr (S >= 2) {
+            constexpr int k = S - 2;
+            __syncthreads();
+            if (tid < lanes(k)) {
+                T out[2];
+                ms_fast_stage<T, C, 2>(S1p[k] + tid, S0p[k] + tid, ms_plane_stride<T>(2), a.h1[k], a.m[k], a.scale[k], out);
+                S1p[k + 1][tid] = out[0];                            // outputs 2 tid, 2 tid + 1 = the next stage's pair tid
+                S0p[k + 1][tid] = out[1];
+            }
+        }
+        {
+            constexpr int k = S - 1;
+            __syncthreads();
+            if (tid < geo.n[k]) {
+                T out[1];
+                ms_fast_stage<T, C, 1>(S1p[k] + tid, S0p[k] + tid, 256, a.h1[k], a.m[k], a.scale[k], out);
+                y[o_first + (long long)tile * geo.F + tid] = out[0];
+            }
+        }
+        __syncthreads();                                             // the next tile overwrites the streams
+    }
+}
+
+template <class T, class C, int S>
+static void launch_ms_fast(const MsDecimArgs<T, C> &a, const MsFastGeom &geo, const T *x, T *y, long long o_first,
+                           long long ntiles, hipStream_t st) {
+    size_t lds = 0;
+    for (int k = 0; k < S; ++k) lds += 2 * (size_t)(1 << (S - 1 - k)) * ms_plane_stride<T>(1 << (S - 1 - k)) * sizeof(T);
+    lds += 64 * sizeof(T);                                           // a lane past the last output may read past its plane
+    int tpw = 1;
+    while (tpw < 8 && ntiles / (2 * tpw) >= 4096) tpw *= 2;
+    const long long nblk = (ntiles + tpw - 1) / tpw;
+    msresamp2_decim_fast_kernel<T, C, S><<<(unsigned)nblk, 256, lds, st>>>(a, geo, x, y, o_first, (int)ntiles, tpw);
+}
+
 template <class T, class C>
 int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const *h1, const T *const *state,
                            T *const *state_next, const T *x, T *y, size_t nout, hipStream_t st) {
@@ -350,17 +516,62 @@ int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const 
         }
     }
     if (lds > 64 * 1024) return fail(YAGI_ERR_INTERNAL, "msresamp2: the fused chain needs %zu bytes of LDS", lds);
-    const size_t tiles = (nout + kMsTile - 1) / kMsTile;
+    // the middle of a long block goes to the fast kernel: tiles of F outputs from the first multiple of 256 whose halo
+    // lies inside the block, the general kernel keeps that head and a tail of at least one output (it writes the windows)
+    long long head_tiles = ((long long)nout + kMsTile - 1) / kMsTile, tail_first = head_tiles * kMsTile;
+    MsFastGeom geo{};
+    long long fast_tiles = 0;
+    if (ns <= 3) {
+        const int R0 = 1 << (ns - 1);
+        for (int F = kMsTile; F >= 64 && !geo.F; --F) {
+            long long n = F, A = 0;
+            int nk[3] = {0, 0, 0};
+            for (int k = ns - 1; k >= 0; --k) {
+                nk[k] = (int)n;
+                if (k > 0) {
+                    n = 2 * (n + 2 * m[k] - 1);
+                    A = 2 * (A + 2 * m[k] - 1);
+                }
+            }
+            const long long cnt0 = n + 2 * m[0] - 1;
+            if (cnt0 <= 256 * R0) {
+                geo.F = F;
+                for (int k = 0; k < 3; ++k) geo.n[k] = nk[k];
+                geo.cnt0 = (int)cnt0;
+                geo.U = (int)(A + 2 * m[0] - 1);
+            }
+        }
+        if (geo.F) {
+            const long long o_min = (geo.U + R0 - 1) / R0;           // first output whose halo starts inside the block
+            const long long head = (o_min + kMsTile - 1) / kMsTile;
+            const long long room = (long long)nout - 1 - head * kMsTile;
+            if (room >= 1024LL * geo.F) {
+                fast_tiles = room / geo.F;
+                head_tiles = head;
+                tail_first = head * kMsTile + fast_tiles * geo.F;
+            }
+        }
+    }
+    const long long tiles = head_tiles + (((long long)nout - tail_first) + kMsTile - 1) / kMsTile;
     // consecutive tiles per workgroup (input prefetch across tiles) while >= ~4096 workgroups remain
     int tpw = 1;
-    while (tpw < 8 && tiles / (size_t)(2 * tpw) >= 4096) tpw *= 2;
-    const size_t nblk = (tiles + tpw - 1) / tpw;
-    if (nblk > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "block too large");
+    while (tpw < 8 && tiles / (2 * tpw) >= 4096) tpw *= 2;
+    const long long nblk = (tiles + tpw - 1) / tpw;
+    if (nblk > 0x7fffffffLL || fast_tiles > 0x7fffffffLL) return fail(YAGI_ERR_CONFIG, "block too large");
+    if (fast_tiles) {
+        const long long o_first = head_tiles * kMsTile;
+        switch (ns) {
+        case 1: launch_ms_fast<T, C, 1>(a, geo, x, y, o_first, fast_tiles, st); break;
+        case 2: launch_ms_fast<T, C, 2>(a, geo, x, y, o_first, fast_tiles, st); break;
+        default: launch_ms_fast<T, C, 3>(a, geo, x, y, o_first, fast_tiles, st); break;
+        }
+        YG_LAUNCH_CHECK();
+    }
     switch (ns) {
-    case 1: msresamp2_decim_kernel<T, C, 1><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
-    case 2: msresamp2_decim_kernel<T, C, 2><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
-    case 3: msresamp2_decim_kernel<T, C, 3><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
-    default: msresamp2_decim_kernel<T, C, 4><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw); break;
+    case 1: msresamp2_decim_kernel<T, C, 1><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw, head_tiles, tail_first); break;
+    case 2: msresamp2_decim_kernel<T, C, 2><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw, head_tiles, tail_first); break;
+    case 3: msresamp2_decim_kernel<T, C, 3><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw, head_tiles, tail_first); break;
+    default: msresamp2_decim_kernel<T, C, 4><<<(unsigned)nblk, 256, lds, st>>>(a, x, y, nout, tpw, head_tiles, tail_first); break;
     }
     YG_LAUNCH_CHECK();
     return YAGI_OK;
