@@ -355,6 +355,29 @@ struct MsFastGeom {
 
 template <class T> struct MsPair { T e, o; };
 
+// The walk over the entries of a lane's R outputs (R = 2, 4): entry t = R g + c feeds output r with tap t - r, so every
+// output sees its taps in rising order.  With 2m = R Q + RHO (RHO = 0, or 2 at R = 4) the set of (c, r) pairs that are taps
+// is fixed per group: g = 0: r <= c; 0 < g < Q: all; g = Q: r > c - RHO; g = Q + 1: r > c + R - RHO -- no run-time checks.
+template <class T, class C, int R, int RHO>
+__device__ __forceinline__ void ms_fast_walk(const T *__restrict__ S1l, int PS, const C *__restrict__ h, int m2, T (&acc)[R]) {
+    const int Q = (m2 - RHO) / R;                                    // >= 1: 2m >= 4
+    auto group = [&](int g, auto tap) {
+        T wv[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) wv[c] = S1l[c * PS + g];
+        const C *hg = h + R * g;
+#pragma unroll
+        for (int c = 0; c < R; ++c)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (tap(c, r)) acc[r] = mac(acc[r], wv[c], hg[c - r]);
+    };
+    group(0, [](int c, int r) { return r <= c; });
+    for (int g = 1; g < Q; ++g) group(g, [](int, int) { return true; });
+    group(Q, [](int c, int r) { return r > c - RHO; });
+    if constexpr (RHO >= 2) group(Q + 1, [](int c, int r) { return r > c + R - RHO; });
+}
+
 // R consecutive outputs of one stage for the lane whose first entry is at S1l / S0l (plane 0, the lane's position)
 template <class T, class C, int R>
 __device__ __forceinline__ void ms_fast_stage(const T *__restrict__ S1l, const T *__restrict__ S0l, int PS,
@@ -366,29 +389,11 @@ __device__ __forceinline__ void ms_fast_stage(const T *__restrict__ S1l, const T
     for (int r = 0; r < R; ++r) acc[r] = zero_of<T>();
     if constexpr (R == 1) {
         acc[0] = r2_branch<T, C>(S1l, h, m2);
+    } else if constexpr (R == 2) {
+        ms_fast_walk<T, C, 2, 0>(S1l, PS, h, m2, acc);
     } else {
-        // entry t = R g + c feeds output r with tap t - r; per output the taps arrive in rising order
-        const int G = (m2 + 2 * R - 2) / R;
-        for (int g = 0; g < G; ++g) {
-            T wv[R];
-#pragma unroll
-            for (int c = 0; c < R; ++c) wv[c] = S1l[c * PS + g];
-            const int t0 = R * g;
-            if (t0 >= R - 1 && t0 + R - 1 < m2) {                    // every (entry, output) pair of the group is a tap
-#pragma unroll
-                for (int c = 0; c < R; ++c)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = mac(acc[r], wv[c], h[t0 + c - r]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < R; ++c)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int kk = t0 + c - r;                   // wave-uniform
-                        if (kk >= 0 && kk < m2) acc[r] = mac(acc[r], wv[c], h[kk]);
-                    }
-            }
-        }
+        if (m2 & 2) ms_fast_walk<T, C, 4, 2>(S1l, PS, h, m2, acc);  // wave-uniform
+        else ms_fast_walk<T, C, 4, 0>(S1l, PS, h, m2, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
