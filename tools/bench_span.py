@@ -3,7 +3,7 @@
 With the pipelined block calls two launches of the kernel are in flight at a time (one per lane of the stream
 object), so the trace's per-launch DURATION (kernel_stats.csv AverageNs) is ~1.7x the launch-to-launch time that
 `roofline.kernel_ms` reports.  This reads the trace itself: the launches on the two lane queues (the two queues that
-carry most launches of the kernel), the last `steps * blocks` of them = the timed region, span / launches.
+carry equally many launches of the kernel), the last `steps * blocks` of them = the timed region, span / launches.
 usage: bench_span.py <kernel_trace.csv> [steps=20] [blocks=16] [kernel substring]"""
 import collections
 import csv
@@ -19,7 +19,10 @@ with open(path) as f:
         if sub in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]))
 cnt = collections.Counter(q for _, _, q in rows)
-lanes = [q for q, _ in cnt.most_common(2)]
+# the two lane queues carry the same number of launches (the blocks alternate between them); the caller's own queue
+# carries the one-stream legs and their warm-up passes, which may be more
+pairs = [(cnt[a] + cnt[b], a, b) for a in cnt for b in cnt if a < b and abs(cnt[a] - cnt[b]) <= 2]
+lanes = list(max(pairs)[1:]) if pairs else [q for q, _ in cnt.most_common(2)]
 lane_rows = sorted(r for r in rows if r[2] in lanes)
 n = steps * blocks
 timed = lane_rows[-n:]
