@@ -150,6 +150,31 @@ def test_large_block_device_path(ya, oracle):
     assert rel_l2(dn.to_numpy(4096, lo), w[8 * m:]) <= 2e-6
 
 
+@pytest.mark.parametrize("kind,m", [("crcf", 12), ("rrrf", 2), ("cccf", 7), ("crcf", 33), ("rrrf", 64), ("crcf", 65)])
+def test_long_decimator_block_equals_short_blocks(ya, oracle, kind, m):
+    """a decimator block of >= 2^19 samples runs as the one-stage case of the MsResamp2 chain kernels (its middle four
+    outputs per lane through msresamp2_decim_fast_kernel; m > 64 stays on resamp2_kernel): the same input cut into
+    blocks below that size goes through resamp2_kernel -- identical bits, windows carried across the calls either way"""
+    hf = oracle.halfband_kaiser(m, 60.0)
+    a, b = ya.Resamp2(kind, hf, m), ya.Resamp2(kind, hf, m)
+    a.set_scale(0.37)
+    b.set_scale(0.37)
+    dt = np.float32 if kind == "rrrf" else np.complex64
+    item = np.dtype(dt).itemsize
+    n1, n2 = (1 << 21) + 2 * 12345, 2 * 777                     # input samples of the two calls
+    x = ya.gen_complex_dev(SEED + 31, n1 + n2)                  # rrrf reads the first half of it as real samples
+    got, want = ya.DeviceArray((n1 + n2) // 2, dt), ya.DeviceArray((n1 + n2) // 2, dt)
+    a.execute_block_dev(ya.Resamp2.DECIM, x.ptr, n1, got.ptr)
+    a.execute_block_dev(ya.Resamp2.DECIM, x.ptr + n1 * item, n2, got.ptr + (n1 // 2) * item)
+    step, off = (1 << 18) + 2 * 101, 0
+    while off < n1 + n2:
+        cnt = min(step, n1 + n2 - off)
+        b.execute_block_dev(ya.Resamp2.DECIM, x.ptr + off * item, cnt, want.ptr + (off // 2) * item)
+        off += cnt
+    ya.synchronize()
+    assert np.array_equal(got.to_numpy(), want.to_numpy()), (kind, m)
+
+
 # ---- MsResamp2 ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ns,fc,as_", [(1, 0.25, 60.0), (2, 0.25, 60.0), (3, 0.25, 60.0), (4, 0.25, 60.0),
                                        (1, 0.45, 60.0), (2, 0.45, 60.0), (3, 0.45, 60.0), (4, 0.45, 60.0),

@@ -2774,8 +2774,19 @@ struct Resamp2Obj {
         if (mode != kR2Filter && mode != kR2Interp && (nx & 1))
             return fail(YAGI_ERR_CONFIG, "resamp2: this form consumes pairs of samples (got %zu)", nx);
         if (nx == 0) return YAGI_OK;
-        YG_TRY((launch_resamp2<T, C>(mode, state[cur].template as<T>(), x, nx, h1d.template as<C>(), m, scale, toggle, y,
-                                     state[1 - cur].template as<T>(), st)));
+        if (mode == kR2Decim && nx >= ((size_t)1 << 19) && m <= 64) {
+            // a long decimator block: the one-stage case of the MsResamp2 chain kernels (the same sums in the same order;
+            // the middle of the block four outputs per lane through msresamp2_decim_fast_kernel)
+            const int mk = m;
+            const C sc = scale;
+            const C *hp = h1d.template as<C>();
+            const T *sp = state[cur].template as<T>();
+            T *sn = state[1 - cur].template as<T>();
+            YG_TRY((launch_msresamp2_decim<T, C>(1, &mk, &sc, &hp, &sp, &sn, x, y, nx / 2, st)));
+        } else {
+            YG_TRY((launch_resamp2<T, C>(mode, state[cur].template as<T>(), x, nx, h1d.template as<C>(), m, scale, toggle, y,
+                                         state[1 - cur].template as<T>(), st)));
+        }
         cur = 1 - cur;
         if (mode == kR2Filter) toggle = (toggle + (int)(nx & 1)) & 1;
         return YAGI_OK;

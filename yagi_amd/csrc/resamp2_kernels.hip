@@ -413,15 +413,17 @@ msresamp2_decim_fast_kernel(MsDecimArgs<T, C> a, MsFastGeom geo, const T *__rest
                             long long o_first, int ntiles, int tpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_lds[];
     static_assert(S >= 1 && S <= 3, "R_0 <= 4");
-    constexpr int R0 = 1 << (S - 1), lgR0 = S - 1;
+    constexpr int RL = S == 1 ? 4 : 1;                               // a single stage (a Resamp2 decimator's block) also runs four per lane
+    constexpr int R0 = RL << (S - 1), lgR0 = S == 1 ? 2 : S - 1;
     const int tid = threadIdx.x;
     // streams: per stage S1 (filter branch), then S0 (delay branch), R_k planes each
     T *S1p[S], *S0p[S];
+    T *Op = nullptr;                                                 // S = 1: the tile's outputs, turned into coalesced stores
     {
         T *p = reinterpret_cast<T *>(ms_lds);
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            const int R = 1 << (S - 1 - k), PS = ms_plane_stride<T>(R);
+            const int R = RL << (S - 1 - k), PS = ms_plane_stride<T>(R);
             S1p[k] = p;
             S0p[k] = p + R * PS;
             p += 2 * R * PS;
@@ -430,6 +432,7 @@ msresamp2_decim_fast_kernel(MsDecimArgs<T, C> a, MsFastGeom geo, const T *__rest
             S1p[2] = S1p[0];                                         // are dead by then (25.6 KB instead of 29.7: six workgroups
             S0p[2] = S1p[0] + 256;                                   // per CU)
         }
+        if constexpr (S == 1) Op = p;
     }
     const int tile0 = blockIdx.x * tpw;
     const int tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
@@ -476,7 +479,23 @@ msresamp2_decim_fast_kernel(MsDecimArgs<T, C> a, MsFastGeom geo, const T *__rest
                 S0p[k + 1][tid] = out[1];
             }
         }
-        {
+        if constexpr (S == 1) {
+            constexpr int PS = ms_plane_stride<T>(4);
+            __syncthreads();
+            if (4 * tid < geo.n[0]) {
+                T out[4];
+                ms_fast_stage<T, C, 4>(S1p[0] + tid, S0p[0] + tid, PS, a.h1[0], a.m[0], a.scale[0], out);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Op[r * PS + tid] = out[r];   // output 4 tid + r: plane r, position tid
+            }
+            __syncthreads();
+            T *yt = y + o_first + (long long)tile * geo.F;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {                                // output j = tid + 256 b: plane j mod 4, position j div 4
+                const int j = tid + 256 * b;
+                if (j < geo.n[0]) yt[j] = Op[(tid & 3) * PS + (tid >> 2) + 64 * b];
+            }
+        } else {
             constexpr int k = S - 1;
             __syncthreads();
             if (tid < geo.n[k]) {
@@ -493,8 +512,10 @@ template <class T, class C, int S>
 static void launch_ms_fast(const MsDecimArgs<T, C> &a, const MsFastGeom &geo, const T *x, T *y, long long o_first,
                            long long ntiles, hipStream_t st) {
     size_t lds = 0;
+    constexpr int RL = S == 1 ? 4 : 1;
     for (int k = 0; k < (S == 3 ? 2 : S); ++k)                       // three stages: the last one's streams lie over stage 0's
-        lds += 2 * (size_t)(1 << (S - 1 - k)) * ms_plane_stride<T>(1 << (S - 1 - k)) * sizeof(T);
+        lds += 2 * (size_t)(RL << (S - 1 - k)) * ms_plane_stride<T>(RL << (S - 1 - k)) * sizeof(T);
+    if (S == 1) lds += 4 * (size_t)ms_plane_stride<T>(4) * sizeof(T);   // the output planes
     lds += 64 * sizeof(T);                                           // a lane past the last output may read past its plane
     // two consecutive tiles per workgroup (the second tile's input in flight during the first): 1 / 2 / 4 / 8 / 16 tiles
     // measure 115.6 / 112.7 / 118.5 / 123.4 / 129.4 us at 2^26 inputs -- many short workgroups interleave better than
@@ -534,8 +555,9 @@ int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const 
     MsFastGeom geo{};
     long long fast_tiles = 0;
     if (ns <= 3) {
-        const int R0 = 1 << (ns - 1);
-        for (int F = kMsTile; F >= 64 && !geo.F; --F) {
+        const int P2 = 1 << (ns - 1);                                 // input pairs per final output
+        const int R0 = ns == 1 ? 4 : P2;                              // pairs per lane and tile
+        for (int F = 256 * R0 / P2; F >= 64 && !geo.F; --F) {
             long long n = F, A = 0;
             int nk[3] = {0, 0, 0};
             for (int k = ns - 1; k >= 0; --k) {
@@ -554,10 +576,10 @@ int launch_msresamp2_decim(int ns, const int *m, const C *scale, const C *const 
             }
         }
         if (geo.F) {
-            const long long o_min = (geo.U + R0 - 1) / R0;           // first output whose halo starts inside the block
+            const long long o_min = (geo.U + P2 - 1) / P2;           // first output whose halo starts inside the block
             const long long head = (o_min + kMsTile - 1) / kMsTile;
             const long long room = (long long)nout - 1 - head * kMsTile;
-            if (room >= 1024LL * geo.F) {
+            if (room >= 1024LL * 231) {                               // from ~2^18 outputs on
                 fast_tiles = room / geo.F;
                 head_tiles = head;
                 tail_first = head * kMsTile + fast_tiles * geo.F;
