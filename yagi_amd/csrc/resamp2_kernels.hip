@@ -520,7 +520,7 @@ static void launch_ms_fast(const MsDecimArgs<T, C> &a, const MsFastGeom &geo, co
     // two consecutive tiles per workgroup (the second tile's input in flight during the first): 1 / 2 / 4 / 8 / 16 tiles
     // measure 115.6 / 112.7 / 118.5 / 123.4 / 129.4 us at 2^26 inputs -- many short workgroups interleave better than
     // a few long ones prefetch
-    const int tpw = 2;
+    const int tpw = S == 1 ? 1 : 2;                                  // one stage: tiles of ~1000 outputs, 1 / 2 / 4 per workgroup: 153.7 / 161.6 / 166.6 us
     const long long nblk = (ntiles + tpw - 1) / tpw;
     msresamp2_decim_fast_kernel<T, C, S><<<(unsigned)nblk, 256, lds, st>>>(a, geo, x, y, o_first, (int)ntiles, tpw);
 }
