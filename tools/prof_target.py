@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiling target: launch each selected kernel a few times (for rocprofv3 --pmc / --kernel-trace).
 usage: python3 tools/prof_target.py [fused fused2 fir2 fir3 fft fft_big chan1 chan2 rrrf63 rrrf256 cccf256
-       decim4x65 decim4x257 decim8x513 interp4 syn2 resamp2 fft16384 fft65536 fft1048576] """
+       decim4x65 decim4x257 decim8x513 interp4 syn2 resamp2 msresamp2 fft16384 fft65536 fft1048576] """
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -65,6 +65,10 @@ for w in what:
         r2 = ya.Resamp2.new("crcf", 12, 0.0, 60.0)
         r2.set_stream(st.cuda_stream)
         fn = lambda r2=r2: r2.execute_block_dev(r2.DECIM, x, n, y)
+    elif w == "msresamp2":
+        ms = ya.MsResamp2("crcf", ya.MsResamp2.DECIM, 3, 0.4, 0.0, 60.0)
+        ms.set_stream(st.cuda_stream)
+        fn = lambda ms=ms: ms.execute_block_dev(x, n // 8, y)
     elif w in ("fft16384", "fft65536", "fft1048576"):
         N = int(w[3:])
         p = ya.Fft(N, ya.Direction.Forward)
