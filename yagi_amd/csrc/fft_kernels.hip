@@ -451,6 +451,99 @@ static int launch_fft_tile256(const FftPlanDev &p, const cf32 *in, cf32 *out, si
     return YAGI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// n = n1 n2 above 8192 points, any factors up to 512 each (10 000 = 100 x 100, 48 000 = 240 x 200, 100 000 = 400 x 250):
+// the four-step form in TWO launches, no transposes -- fft_twopass_kernel's scheme with the mixed-radix LDS passes of
+// fft_mixed_kernel.  x viewed as [n1][n2]:
+//   MODE 0 (columns): a workgroup takes nfr consecutive columns (rows of nfr consecutive points in memory: 128-byte
+//           runs at nfr = 16, 64-byte runs at 8), transforms them over n1 and writes S[k1][c] = W_n^{k1 c} FFT_n1{x[.][c]}[k1]
+//   MODE 1 (rows):    a workgroup takes nfr consecutive rows k1 of S (one contiguous piece), transforms them over n2 and
+//           writes X[k2 n1 + k1]: runs of nfr points again.
+// Two HBM round trips instead of the five of launch_fft_four_step.  W_n^m = whi[m >> 12] wlo[m & 4095] (exact split tables).
+// ---------------------------------------------------------------------------------------------
+template <int SIGN, int MODE>
+__global__ void __launch_bounds__(256)
+fft_mixed_twopass_kernel(FftPlanDev p, const float2 *__restrict__ in, float2 *__restrict__ out,
+                         const float2 *__restrict__ wlo, const float2 *__restrict__ whi, int n1, int n2, int nfr) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = p.n;                                           // n1 (MODE 0) / n2 (MODE 1)
+    float2 *bufA = reinterpret_cast<float2 *>(smem);
+    float2 *bufB = bufA + (size_t)nfr * N;
+    const float2 *tw = reinterpret_cast<const float2 *>(p.tw);
+    const size_t n = (size_t)n1 * n2;
+    const float2 *gsrc = in + blockIdx.y * n;
+    float2 *gdst = out + blockIdx.y * n;
+    const int t0 = blockIdx.x * nfr;                             // first column (MODE 0) / row (MODE 1) of the tile
+    const int left = (MODE == 0 ? n2 : n1) - t0;
+    const int nb = left < nfr ? left : nfr;
+    const int total = nb * N;
+    if (MODE == 0)
+        batched_for<256>(total, [&](int e) { const int pp = e / nb, tr = e - pp * nb; return gsrc[(size_t)pp * n2 + t0 + tr]; },
+                         [&](int e, float2 v) { const int pp = e / nb, tr = e - pp * nb; bufA[tr * N + pp] = v; });
+    else
+        batched_for<256>(total, [&](int e) { return gsrc[(size_t)t0 * n2 + e]; }, [&](int e, float2 v) { bufA[e] = v; });
+    __syncthreads();
+    float2 *src = bufA, *dst = bufB;
+    int Ns = 1;
+    for (int f = 0; f < p.nfac; ++f) {
+        const int R = p.fac[f];
+        switch (R) {
+            case 16: stockham_pass_any<16, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 8: stockham_pass_any<8, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 7: stockham_pass_any<7, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 5: stockham_pass_any<5, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 4: stockham_pass_any<4, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 3: stockham_pass_any<3, SIGN>(src, dst, N, Ns, nb, tw); break;
+            case 2: stockham_pass_any<2, SIGN>(src, dst, N, Ns, nb, tw); break;
+            default: stockham_pass_direct(src, dst, N, R, Ns, nb, tw); break;
+        }
+        __syncthreads();
+        float2 *tmp = src; src = dst; dst = tmp;
+        Ns *= R;
+    }
+    const size_t opitch = MODE == 0 ? (size_t)n2 : (size_t)n1;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int k = e / nb, tr = e - k * nb;
+        float2 v = src[tr * N + k];
+        if (MODE == 0) {
+            const unsigned m = (unsigned)k * (unsigned)(t0 + tr);       // < n1 n2
+            v = cmul(v, cmul(whi[m >> 12], wlo[m & 4095u]));
+        }
+        gdst[(size_t)k * opitch + t0 + tr] = v;
+    }
+}
+
+static int launch_fft_mixed_two_pass(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
+    const int n1 = p.fs_n1, n2 = p.fs_n2;
+    const size_t n = (size_t)p.n;
+    float2 *s0 = reinterpret_cast<float2 *>(p.fs_scratch);
+    const float2 *wlo = reinterpret_cast<const float2 *>(p.fs_wlo4), *whi = reinterpret_cast<const float2 *>(p.fs_whi4);
+    const bool fwd = p.dir == YAGI_FFT_FORWARD;
+    auto pass = [&](int mode, const FftPlanDev &f, const float2 *src, float2 *dst, unsigned nb) -> int {
+        const int nfr = f.n <= 128 ? 16 : 8;                      // 16 up to N = 256 measures 15-26 % slower at 48 000 / 100 000 (LDS per workgroup)
+        const size_t lds = 2 * (size_t)nfr * f.n * sizeof(float2);
+        const dim3 grid((unsigned)(((mode == 0 ? n2 : n1) + nfr - 1) / nfr), nb);
+        if (mode == 0) {
+            if (fwd) fft_mixed_twopass_kernel<-1, 0><<<grid, 256, lds, st>>>(f, src, dst, wlo, whi, n1, n2, nfr);
+            else fft_mixed_twopass_kernel<+1, 0><<<grid, 256, lds, st>>>(f, src, dst, wlo, whi, n1, n2, nfr);
+        } else {
+            if (fwd) fft_mixed_twopass_kernel<-1, 1><<<grid, 256, lds, st>>>(f, src, dst, wlo, whi, n1, n2, nfr);
+            else fft_mixed_twopass_kernel<+1, 1><<<grid, 256, lds, st>>>(f, src, dst, wlo, whi, n1, n2, nfr);
+        }
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    };
+    const size_t chunk = (size_t)p.fs_chunk * 2;                 // the whole scratch holds the one intermediate (half of it: 3-8 % slower)
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const unsigned nb = (unsigned)((batch - b0) < chunk ? (batch - b0) : chunk);
+        const float2 *src = reinterpret_cast<const float2 *>(in) + b0 * n;
+        float2 *dst = reinterpret_cast<float2 *>(out) + b0 * n;
+        YG_TRY(pass(0, *p.fs_p1, src, s0, nb));
+        YG_TRY(pass(1, *p.fs_p2, s0, dst, nb));
+    }
+    return YAGI_OK;
+}
+
 static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int n1 = p.fs_n1, n2 = p.fs_n2;
     const size_t n = (size_t)p.n;
@@ -526,6 +619,8 @@ int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batc
     if (p.bs_m) return launch_fft_bluestein(p, in, out, batch, st);
     if (p.fs_n1 && p.fs_wlo) return launch_fft_tile256(p, in, out, batch, st);
     if (p.fs_n1 && p.fs_wn) return launch_fft_two_pass(p, in, out, batch, st);
+    if (p.fs_n1 && p.fs_n1 <= kFftTwoPassMixedMax && p.fs_n2 <= kFftTwoPassMixedMax && p.fs_p1->nfac && p.fs_p2->nfac)
+        return launch_fft_mixed_two_pass(p, in, out, batch, st);
     if (p.fs_n1) return launch_fft_four_step(p, in, out, batch, st);
     if (p.n > kFftMaxLds) return fail(YAGI_ERR_INTERNAL, "fft size %d has no plan resources", p.n);
     if (p.n == 8192) {
