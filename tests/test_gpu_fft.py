@@ -51,7 +51,8 @@ def test_fft_config(ya):
     assert np.array_equal(ya.Fft(1, ya.Direction.Forward).run(np.complex64([3 - 2j])), np.complex64([3 - 2j]))
 
 
-@pytest.mark.parametrize("n", [2, 16, 32, 64, 128, 256, 512, 1000, 1024, 2048, 3125, 4096, 8192, 4093])
+@pytest.mark.parametrize("n", [2, 16, 32, 64, 128, 256, 512, 1000, 1024, 2048, 3125, 4096, 8192, 4093,
+                               1031, 2039, 2042, 2053, 4083, 4095 - 4])   # the last six: Bluestein in one kernel, m = 4096 / 8192
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_vs_f64_definition(ya, oracle, n, direction):
     """parity unpinned by the reference above N = 509; pinned by the definition (f64 DFT)."""
@@ -122,10 +123,11 @@ def test_config_c3_fft_4096_batch_65536(ya, oracle):
     dy.free()
 
 
-@pytest.mark.parametrize("n", [16, 128, 256, 512, 1024, 2048, 8192, 100, 1000, 509])
+@pytest.mark.parametrize("n", [16, 128, 256, 512, 1024, 2048, 8192, 100, 1000, 509, 2039, 4093])
 def test_fft_large_batch_on_device(ya, oracle, n):
     """many workgroups / several transforms per workgroup / a partial last workgroup (and, for 509, several
-    passes through the Bluestein scratch): 2^21+ points on device buffers, sampled transforms vs the f64 DFT"""
+    passes through the Bluestein scratch; 2039 and 4093: the one-kernel Bluestein form, odd n = transforms that start
+    on 8-byte boundaries only): 2^21+ points on device buffers, sampled transforms vs the f64 DFT"""
     batch = (1 << 21) // n + 3
     dx = ya.gen_complex_dev(SEED + 3, batch * n)
     dy = ya.DeviceArray(batch * n, np.complex64)

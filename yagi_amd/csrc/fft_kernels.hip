@@ -570,8 +570,83 @@ static int launch_fft_four_step(const FftPlanDev &p, const cf32 *in, cf32 *out, 
     return YAGI_OK;
 }
 
+// Bluestein with m = 4096 or 8192 (1024 < n <= 4096 with a prime factor above 89) in ONE kernel: a workgroup owns one
+// transform -- x w zero-padded to m, FFT_m, times FFT_m{b}, inverse FFT_m, times w / m -- with the m-point transforms
+// chained in registers (fft4096_passes_to_regs leaves X[t + 256 d] where its first pass expects x[256 a + t]).
+// n points in, n points out: 16 B per point instead of the ~240 of the five launches; the chirp, FFT{b} and twiddle
+// tables come from L2.  m = 8192: forward by decimation in time (even / odd samples -> two 4096-point transforms ->
+// X[k], X[k + 4096]), inverse by decimation in frequency (Y[k] +- Y[k + 4096] -> two 4096-point transforms -> even / odd
+// samples), so the register layouts meet without an exchange.
+template <int M8K>
+__global__ void __launch_bounds__(256)
+bluestein_fused_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ w,
+                       const float2 *__restrict__ bf, const float2 *__restrict__ twf, const float2 *__restrict__ twb, int n) {
+    __shared__ float2 lds[kFft4096LdsFloat2];
+    const unsigned t = threadIdx.x;
+    const float2 *src = in + (size_t)blockIdx.x * n;
+    float2 *dst = out + (size_t)blockIdx.x * n;
+    const float2 zero = make_float2(0.f, 0.f);
+    if constexpr (!M8K) {
+        const float inv = 1.0f / 4096.0f;
+        float2 v[16];
+#pragma unroll
+        for (unsigned a = 0; a < 16; ++a) {
+            const unsigned k = 256u * a + t;
+            v[a] = (int)k < n ? cmul(src[k], w[k]) : zero;
+        }
+        fft4096_passes_to_regs<-1>(v, lds, twf);
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) v[d] = cmul(v[d], bf[t + 256u * d]);
+        fft4096_passes_to_regs<+1>(v, lds, twb);
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) {
+            const unsigned k = t + 256u * d;
+            if ((int)k < n) dst[k] = cscale(cmul(v[d], w[k]), inv);
+        }
+    } else {
+        const float inv = 1.0f / 8192.0f;
+        const float2 *twf4 = twf + 8192, *twb4 = twb + 8192;     // the W_4096 tables behind the W_8192 ones
+        float2 e[16], o[16];
+#pragma unroll
+        for (unsigned a = 0; a < 16; ++a) {
+            const unsigned k = 2u * (256u * a + t);
+            e[a] = (int)k < n ? cmul(src[k], w[k]) : zero;
+            o[a] = (int)(k + 1) < n ? cmul(src[k + 1], w[k + 1]) : zero;
+        }
+        fft4096_passes_to_regs<-1>(e, lds, twf4);
+        fft4096_passes_to_regs<-1>(o, lds, twf4);
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) {
+            const unsigned k = t + 256u * d;
+            const float2 p = cmul(o[d], twf[k]);
+            const float2 y0 = cmul(cadd(e[d], p), bf[k]), y1 = cmul(csub(e[d], p), bf[k + 4096]);
+            e[d] = cadd(y0, y1);
+            o[d] = cmul(csub(y0, y1), twb[k]);
+        }
+        fft4096_passes_to_regs<+1>(e, lds, twb4);
+        fft4096_passes_to_regs<+1>(o, lds, twb4);
+#pragma unroll
+        for (unsigned d = 0; d < 16; ++d) {
+            const unsigned k = 2u * (t + 256u * d);
+            if ((int)k < n) dst[k] = cscale(cmul(e[d], w[k]), inv);
+            if ((int)(k + 1) < n) dst[k + 1] = cscale(cmul(o[d], w[k + 1]), inv);
+        }
+    }
+}
+
 static int launch_fft_bluestein(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st) {
     const int m = p.bs_m;
+    if ((m == 4096 || m == 8192) && !p.bs_fwd) {
+        if (batch > 0x7fffffffull) return fail(YAGI_ERR_CONFIG, "batch too large");
+        const float2 *fin = reinterpret_cast<const float2 *>(in), *w = reinterpret_cast<const float2 *>(p.bs_w);
+        const float2 *bf = reinterpret_cast<const float2 *>(p.bs_bf);
+        const float2 *twf = reinterpret_cast<const float2 *>(p.bs_twf), *twb = reinterpret_cast<const float2 *>(p.bs_twb);
+        float2 *fout = reinterpret_cast<float2 *>(out);
+        if (m == 4096) bluestein_fused_kernel<0><<<(unsigned)batch, 256, 0, st>>>(fin, fout, w, bf, twf, twb, p.n);
+        else bluestein_fused_kernel<1><<<(unsigned)batch, 256, 0, st>>>(fin, fout, w, bf, twf, twb, p.n);
+        YG_LAUNCH_CHECK();
+        return YAGI_OK;
+    }
     FftPlanDev fwd, bwd;
     if (p.bs_fwd && p.bs_bwd) {          // m > 8192: full plans with their own (four-step) resources
         fwd = *p.bs_fwd;
