@@ -232,6 +232,11 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
     for (int n = 1; n < P; ++n)
         w[P - n] = load_hist(hist, hist_len, x, (f_begin - n) * M + c, x_len);
     float2 xa[kColHalf], xb[kColHalf];               // the next two half tiles of this column, in flight
+    // M = 64 with 16 taps: ONE half tile in flight.  With two, the kernel holds 150 VGPRs = three waves per SIMD; with one,
+    // 124 = four, and at 4096 workgroups (four rounds of the 1024 resident ones) it measures 214.9 us against 227.9 us
+    // for two in flight at 2048 workgroups (1024 / 2048 workgroups with one in flight: 233.0 / 235.6 us)
+    constexpr bool kOneInFlight = LGM == 6 && P == 16;
+    constexpr int kAhead = kOneInFlight ? kColHalf : kColTile;
     // A full workgroup addresses its samples and outputs through buffer descriptors: one VGPR byte offset per lane,
     // the frame steps in SGPRs -- no 64-bit address arithmetic, no per-frame checks.
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + wg_first * M, 0xffffffffu);
@@ -263,7 +268,7 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
             }
             va[(g * kColHalf + j) * pitch + c] = acc;
         }
-        if (t + kColTile < run) load8(xin, t + kColTile);
+        if (t + kAhead < run) load8(xin, t + kAhead);
         __syncthreads();
         stockham_pass<R0, -1, true>(va, vb, M, 1, nq, twl, 1, true, pitch, lgnq);
         __syncthreads();
@@ -299,10 +304,11 @@ firpfbch_col_kernel(const float2 *__restrict__ hist, const float2 *__restrict__ 
         __syncthreads();
     };
     load8(xa, 0);
-    load8(xb, kColHalf);
+    if constexpr (!kOneInFlight) load8(xb, kColHalf);
     for (int t0 = 0; t0 < run; t0 += kColTile) {
         half_tile(xa, t0, std::integral_constant<int, 0>{});
-        half_tile(xb, t0 + kColHalf, std::integral_constant<int, kColHalf>{});
+        if constexpr (kOneInFlight) half_tile(xa, t0 + kColHalf, std::integral_constant<int, kColHalf>{});
+        else half_tile(xb, t0 + kColHalf, std::integral_constant<int, kColHalf>{});
     }
 }
 
@@ -313,8 +319,9 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
     // >= ~2048 workgroups
-    // M = 64: 2048 workgroups measure 6-8 % faster than 1024 (8192: 4 % slower) although each run re-reads its p - 1 frames of history
-    size_t run = nframes / ((LGM == 6 ? 2 * kColWgs : kColWgs) * G);
+    // M = 64: 2048 workgroups measure 6-8 % faster than 1024 (8192: 4 % slower) although each run re-reads its p - 1 frames of
+    // history; with 16 taps (one half tile in flight, four resident workgroups per CU) 4096
+    size_t run = nframes / ((LGM == 6 ? (P == 16 ? 4 : 2) * kColWgs : kColWgs) * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 256) run = 256;
