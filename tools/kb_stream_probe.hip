@@ -1,5 +1,7 @@
 // kb_stream_probe.hip -- what a kernel that does nothing but move float2 frames reaches on this device for a given
-// read : write mix (diagnostic, built and run by tools/kb_stream_probe.py on the GPU box; not part of the library).
+// read : write mix (diagnostic, not part of the library).  Build here, run on the GPU box (the binary travels with gpurun):
+//   hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result tools/kb_stream_probe.hip -o tools/kb_stream_probe
+//   gpurun -- 'tools/kb_stream_probe > gpurun_out/stream_probe.txt'        (profiles/r03_stream_probe.txt)
 // One 256-lane workgroup per 32 KiB unit, like the path's frame kernels: R loads and W stores of 2 KiB rows per lane.
 #include <hip/hip_runtime.h>
 #include <cstdio>
