@@ -602,7 +602,10 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
         }
         YG_TRY(p.bs_w.alloc(n * sizeof(cf32)));
         YG_TRY(upload(p.bs_w.p, w.data(), n * sizeof(cf32), nullptr));
-        size_t chunk = ((size_t)1 << 21) / m;                  // 2 x 16 MiB of scratch (more for one big transform)
+        // 2 x 64 MiB of scratch (more for one big transform).  With 2 x 16 MiB the five-stage form was launch-bound on long
+        // batches (n = 12 289: 2400 launches of ~9 us for 2^28 points): 0.20 -> 0.30 TB/s, n = 509: 0.42 -> 0.59; 2 x 128 MiB the same
+        static const int bs_lg = getenv("YAGI_HIP_BS_CHUNK_LOG2") ? atoi(getenv("YAGI_HIP_BS_CHUNK_LOG2")) : 23;
+        size_t chunk = ((size_t)1 << (bs_lg < 16 ? 16 : (bs_lg > 26 ? 26 : bs_lg))) / m;
         if (chunk < 1) chunk = 1;
         YG_TRY(p.bs_scratch.alloc(2 * chunk * m * sizeof(cf32)));
         YG_TRY(p.bs_bf.alloc(m * sizeof(cf32)));
