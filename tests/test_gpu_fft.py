@@ -140,14 +140,15 @@ def test_fft_large_batch_on_device(ya, oracle, n):
 
 
 @pytest.mark.parametrize("n", [16384, 32768, 65536, 1 << 17, 1 << 20, 1 << 22, 1 << 24, 10000, 12289, 8193, 100003, 48000, 100000, 30030, 9973 * 4,
-                               9216, 250000, 130321, 512 * 511, 1000000])
+                               9216, 250000, 130321, 512 * 511, 1000000, 3000000])
 @pytest.mark.parametrize("direction", ["Forward", "Backward"])
 def test_fft_beyond_one_workgroup(ya, n, direction):
     """n > 8192: 2^14 and 2^15 by the two-launch column / row form over the LDS core, powers of two from 2^16 up as
     256 x n2 (256-point columns in registers, then the n2-point rows: two launches at 2^16, three above), smooth
-    sizes with both factors up to 512 by the two-launch mixed-radix form (fft_mixed_twopass_kernel; 10 000 = 100 x 100
-    with a ragged last column tile, 130 321 = 361 x 361 with radix-19 direct sums), larger smooth sizes by the four-step
-    form (transposes around the register kernels, 10^6), every other size by Bluestein over a power of two.
+    sizes with both factors up to 1024 by the two-launch mixed-radix form (fft_mixed_twopass_kernel; 10 000 = 100 x 100
+    with a ragged last column tile, 130 321 = 361 x 361 with radix-19 direct sums, 10^6 = 1000 x 1000 with four columns
+    per workgroup), larger smooth sizes by the four-step form (transposes around the one-kernel transforms: 3 x 10^6 =
+    2000 x 1500), every other size by Bluestein over a power of two.
     Truth: numpy's f64 FFT of the same f32 samples."""
     rng = np.random.default_rng(n)
     batch = 2 if n < (1 << 22) else 1

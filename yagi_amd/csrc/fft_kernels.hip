@@ -452,7 +452,7 @@ static int launch_fft_tile256(const FftPlanDev &p, const cf32 *in, cf32 *out, si
 }
 
 // ---------------------------------------------------------------------------------------------
-// n = n1 n2 above 8192 points, any factors up to 512 each (10 000 = 100 x 100, 48 000 = 240 x 200, 100 000 = 400 x 250):
+// n = n1 n2 above 8192 points, any factors up to 1024 each (10 000 = 100 x 100, 48 000 = 240 x 200, 100 000 = 400 x 250):
 // the four-step form in TWO launches, no transposes -- fft_twopass_kernel's scheme with the mixed-radix LDS passes of
 // fft_mixed_kernel.  x viewed as [n1][n2]:
 //   MODE 0 (columns): a workgroup takes nfr consecutive columns (rows of nfr consecutive points in memory: 128-byte
@@ -520,7 +520,9 @@ static int launch_fft_mixed_two_pass(const FftPlanDev &p, const cf32 *in, cf32 *
     const float2 *wlo = reinterpret_cast<const float2 *>(p.fs_wlo4), *whi = reinterpret_cast<const float2 *>(p.fs_whi4);
     const bool fwd = p.dir == YAGI_FFT_FORWARD;
     auto pass = [&](int mode, const FftPlanDev &f, const float2 *src, float2 *dst, unsigned nb) -> int {
-        const int nfr = f.n <= 128 ? 16 : 8;                      // 16 up to N = 256 measures 15-26 % slower at 48 000 / 100 000 (LDS per workgroup)
+        // columns / rows per workgroup: 16 up to N = 128, 8 up to 512 (16 there: 15-26 % slower at 48 000 / 100 000, LDS per
+        // workgroup), 4 up to 1024 (32-byte runs, still ahead of the five-trip form: 360 000 -22 %, 600 000 -17 %, 10^6 -2 %)
+        const int nfr = f.n <= 128 ? 16 : (f.n <= 512 ? 8 : 4);
         const size_t lds = 2 * (size_t)nfr * f.n * sizeof(float2);
         const dim3 grid((unsigned)(((mode == 0 ? n2 : n1) + nfr - 1) / nfr), nb);
         if (mode == 0) {

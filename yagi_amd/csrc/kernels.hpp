@@ -157,7 +157,7 @@ struct FftPlanDev {
     const cf32 *fs_wlo = nullptr, *fs_whi = nullptr;   // n = 256 n2 >= 2^16 (fft_tile256_kernel): W_n^j, j < 4096, and W_n^{4096 j}
 };
 constexpr int kFftMaxLds = 8192;     // complex points held in LDS by the one-kernel path
-constexpr int kFftTwoPassMixedMax = 512;   // n = n1 n2 with both factors up to this: two launches (fft_mixed_twopass_kernel)
+constexpr int kFftTwoPassMixedMax = 1024;  // n = n1 n2 with both factors up to this: two launches (fft_mixed_twopass_kernel)
 constexpr size_t kFftMaxPow2 = (size_t)1 << 24;    // largest power of two (four-step); any other n up to 2^23 (Bluestein)
 int launch_fft_batch(const FftPlanDev &p, const cf32 *in, cf32 *out, size_t batch, hipStream_t st);
 int launch_fft_shift(cf32 *buf, size_t n, size_t batch, hipStream_t st);
