@@ -607,6 +607,7 @@ static int fft_plan_init(FftPlan &p, size_t n, int dir) {
         static const int bs_lg = getenv("YAGI_HIP_BS_CHUNK_LOG2") ? atoi(getenv("YAGI_HIP_BS_CHUNK_LOG2")) : 23;
         size_t chunk = ((size_t)1 << (bs_lg < 16 ? 16 : (bs_lg > 26 ? 26 : bs_lg))) / m;
         if (chunk < 1) chunk = 1;
+        if (m == 4096 || m == 8192) chunk = 1;                 // bluestein_fused_kernel: the scratch only serves FFT_m{b} below
         YG_TRY(p.bs_scratch.alloc(2 * chunk * m * sizeof(cf32)));
         YG_TRY(p.bs_bf.alloc(m * sizeof(cf32)));
         FftPlanDev f;                                          // FFT_m of the chirp filter by the device transform itself
