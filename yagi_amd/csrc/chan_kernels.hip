@@ -319,9 +319,15 @@ static int launch_firpfbch_col(const cf32 *hist, const cf32 *x, const float *h, 
     const int G = 256 / M;
     // run length per column group: long enough to amortise the (p-1)-frame halo, short enough for
     // >= ~2048 workgroups
-    // M = 64: 2048 workgroups measure 6-8 % faster than 1024 (8192: 4 % slower) although each run re-reads its p - 1 frames of
-    // history; with 16 taps (one half tile in flight, four resident workgroups per CU) 4096
-    size_t run = nframes / ((LGM == 6 ? (P == 16 ? 4 : 2) * kColWgs : kColWgs) * G);
+    // M = 64 on long blocks: 2048 workgroups measure 6-8 % faster than 1024 (8192: 4 % slower) although each run re-reads its
+    // p - 1 frames of history; with 16 taps (one half tile in flight, four resident workgroups per CU) 4096.  Shorter blocks
+    // keep runs of >= 64 (128) frames -- at 2^24 samples 4096 workgroups would leave runs of 16 frames: 1.46x read traffic, +5 %
+    size_t wgs = kColWgs;
+    if (LGM == 6) {
+        const size_t most = (P == 16 ? 4 : 2) * kColWgs, want = nframes / ((size_t)G * (P == 16 ? 64 : 128));
+        wgs = want < kColWgs ? kColWgs : (want > most ? most : want);
+    }
+    size_t run = nframes / (wgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 256) run = 256;
@@ -1089,8 +1095,14 @@ static int launch_firpfbch2_col(const cf32 *hist, int hist_len, const cf32 *x, c
                                 cf32 *hist_next, int p_real) {
     constexpr int M = 1 << LGM;
     const int G = 256 / M;
-    // M = 256: 4096 workgroups measure 3.5-4 % faster than 1024 (8192 the same)
-    size_t run = nsteps / ((LGM == 8 ? 4 * kColWgs : kColWgs) * G);
+    // M = 256 on long blocks: 4096 workgroups measure 3.5-4 % faster than 1024 (8192 the same); shorter blocks keep runs of
+    // >= 128 steps (at 2^24 samples 4096 workgroups leave runs of 32 steps: 1.47x read traffic, 99.8 us against 85.1 us)
+    size_t wgs = kColWgs;
+    if (LGM == 8) {
+        const size_t want = nsteps / ((size_t)G * 128);
+        wgs = want < kColWgs ? kColWgs : (want > 4 * kColWgs ? 4 * kColWgs : want);
+    }
+    size_t run = nsteps / (wgs * G);
     run = run / kColTile * kColTile;
     if (run < (size_t)kColTile) run = kColTile;
     if (run > 512) run = 512;
